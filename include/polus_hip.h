@@ -1,0 +1,180 @@
+/* polus_hip.h — C ABI of libpolus_hip.so, the MI355X (gfx950) kernel library behind the
+ * Polus training hot path.
+ *
+ * The reference (bioinformatics-ua/polus @ 0.2.1) has NO native interface: every numeric
+ * instruction of `BaseTrainer.train_step` (polus/training.py:150-193) is executed by
+ * third-party wheels (TensorFlow/Keras, HuggingFace TF-BERT, tensorflow-addons, Horovod).
+ * Each entry point below therefore cites the reference call site whose arithmetic it
+ * replaces.  Conventions:
+ *   - every function returns 0 on success; on failure a non-zero code and a thread-local
+ *     message from polus_last_error();
+ *   - every pointer is a caller-owned DEVICE pointer (HBM) unless the name says host;
+ *     nothing is allocated inside a call — scratch is passed as (workspace, bytes) and
+ *     sized with the matching *_workspace_bytes();
+ *   - every launch goes to the caller's stream (`void* stream` is a hipStream_t);
+ *     no call synchronises;
+ *   - activations are row-major [rows, features]; Dense weights are [out, in]
+ *     (PyTorch layout — the reference loads its BERT weights `from_pt=True`,
+ *     polus/models.py:229);
+ *   - `dtype` selects the activation/weight element type: POLUS_F32 (exact-f32 MFMA,
+ *     the parity path) or POLUS_BF16 (bf16 MFMA inputs, f32 accumulation).  Biases,
+ *     LayerNorm parameters, statistics, losses, gradients of parameters and optimizer
+ *     state are always f32.
+ */
+#ifndef POLUS_HIP_H
+#define POLUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLUS_ABI_VERSION 1
+
+enum { POLUS_OK = 0, POLUS_ERR_INVALID = 1, POLUS_ERR_HIP = 2, POLUS_ERR_WORKSPACE = 3 };
+enum { POLUS_F32 = 0, POLUS_BF16 = 1 };
+/* operand storage for polus_gemm: K_CONTIG = [rows][K] (K fastest), K_STRIDED = [K][rows] */
+enum { POLUS_K_CONTIG = 0, POLUS_K_STRIDED = 1 };
+enum { POLUS_ACT_NONE = 0, POLUS_ACT_GELU = 1, POLUS_ACT_SWISH = 2, POLUS_ACT_RELU = 3, POLUS_ACT_TANH = 4 };
+/* polus_gemm flags */
+enum {
+    POLUS_GEMM_ACCUM_C = 1,  /* C += result (gradient accumulation)                         */
+    POLUS_GEMM_ACT_FWD = 2,  /* aux[m][n] = v (pre-activation, if aux != NULL); C = act(v)   */
+    POLUS_GEMM_ACT_BWD = 4   /* C = v * act'(aux[m][n])                                      */
+};
+
+const char* polus_last_error(void);
+int polus_abi_version(void);
+/* host out-params; arch is a NUL-terminated gcnArchName prefix (e.g. "gfx950") */
+int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ---- GEMM (HF Dense layers + their gradients; tape.gradient at polus/training.py:185)
+ * C[M,N] = epilogue(alpha * A_op[M,K] . B_op[K,N]).
+ *   a_layout: K_CONTIG  -> A stored [M][K] (lda = row stride), K_STRIDED -> stored [K][M]
+ *   b_layout: K_CONTIG  -> B stored [N][K] (ldb),              K_STRIDED -> stored [K][N]
+ *   forward  Y = X W^T        : A=X (K_CONTIG), B=W[out,in] (K_CONTIG)
+ *   dX = dY W                 : A=dY (K_CONTIG), B=W[out,in] (K_STRIDED)
+ *   dW = dY^T X               : A=dY (K_STRIDED), B=X (K_STRIDED), c_dtype = POLUS_F32
+ * epilogue order: v = alpha*acc; v += bias[n]; ACT_FWD: aux=v, v=act(v); ACT_BWD: v*=act'(aux);
+ *                 v += resid[m][n]; ACCUM_C: v += C[m][n]; C = v.
+ * c_dtype is the element type of C / resid / aux... C only: resid and aux use `dtype`.
+ * split_k > 1 writes f32 partial slabs to `workspace` and reduces them in a second,
+ * order-fixed kernel (bitwise reproducible); only bias/ACCUM_C epilogues are allowed then. */
+size_t polus_gemm_workspace_bytes(int M, int N, int split_k);
+int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
+               const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+               int M, int N, int K, float alpha,
+               const float* bias, const void* resid, long ldr, void* aux, long ldaux,
+               int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* ---- fused scaled-dot-product attention (HF TFBertSelfAttention as driven by
+ * TFBertSplited.call, polus/models.py:201-216, with the additive key mask
+ * (1-m)*-10000 of polus/models.py:175-195).
+ * qkv   [B*S, 3H] fused projections, row blocks Q | K | V, head h at columns h*64..h*64+63
+ * mask  [B, S] int32 {0,1} (NULL = all ones)
+ * ctx   [B*S, H]; lse [B, A, S] f32 = log-sum-exp of the masked, scaled scores
+ * head_dim must be 64.  Backward recomputes the probabilities from lse; dqkv [B*S, 3H].
+ * workspace for bwd: B*A*S floats (row dot products dO.O). */
+int polus_attention_fwd(int dtype, const void* qkv, const int32_t* mask, void* ctx, float* lse,
+                        int B, int S, int n_heads, int head_dim, void* stream);
+size_t polus_attention_bwd_workspace_bytes(int B, int S, int n_heads);
+int polus_attention_bwd(int dtype, const void* qkv, const int32_t* mask, const void* ctx,
+                        const void* dctx, const float* lse, void* dqkv,
+                        int B, int S, int n_heads, int head_dim,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm over the feature axis, eps inside the sqrt, biased variance
+ * (HF TFBertSelfOutput/TFBertOutput/TFBertEmbeddings LayerNorm, eps 1e-12).
+ * fwd: y = (x-mean)*rstd*gamma+beta; mean/rstd [rows] f32 are saved for backward.
+ * bwd: dx; dgamma/dbeta [H] f32 (+= when accumulate); if dbias != NULL also
+ *      dbias[H] (+)= column sums of dx (the bias gradient of the Dense that produced x). */
+size_t polus_layernorm_bwd_workspace_bytes(int rows, int H);
+int polus_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta,
+                        void* y, float* mean, float* rstd, int rows, int H, float eps, void* stream);
+int polus_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+                        const float* mean, const float* rstd, void* dx,
+                        float* dgamma, float* dbeta, float* dbias, int accumulate,
+                        int rows, int H, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- embeddings: word[ids] + pos[s] + type[tt] -> LayerNorm (HF TFBertEmbeddings; TF gather
+ * has no padding_idx, so row 0 receives its gradient).  Tables and their gradients are f32.
+ * bwd recomputes the pre-LN sum; gword rows are accumulated with f32 atomics unless
+ * `deterministic`, in which case duplicates are summed in index order by one owner wave. */
+size_t polus_embed_bwd_workspace_bytes(int B, int S, int H);
+int polus_embed_ln_fwd(int dtype, const int32_t* ids, const int32_t* type_ids,
+                       const float* word, const float* pos, const float* type,
+                       const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                       int B, int S, int H, int vocab, int max_pos, int type_vocab, float eps,
+                       void* stream);
+int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids, const int32_t* type_ids,
+                       const float* word, const float* pos, const float* type, const float* gamma,
+                       const float* mean, const float* rstd,
+                       float* gword, float* gpos, float* gtype, float* ggamma, float* gbeta,
+                       int accumulate, int deterministic,
+                       int B, int S, int H, int vocab, int max_pos, int type_vocab,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- column sums out[c] (+)= sum_r x[r][c]  (bias gradients) */
+size_t polus_colsum_workspace_bytes(int rows, int cols);
+int polus_colsum(int dtype, const void* x, long ldx, int rows, int cols, float* out, int accumulate,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- losses.  logits are f32 [rows, C] (ld = ldl); dlogits is written in `dtype` (ld = lddl)
+ * already divided by `rows` (tf.reduce_mean over every leading dim); loss is one f32.
+ * softmax_xent: Keras SparseCategoricalCrossentropy(from_logits=True)
+ *   (tutorials/classifier_example.py:55); class_weights != NULL gives polus/losses.py:5-18
+ *   with one-hot targets (weight = class_weights[label]).
+ * sigmoid_xent: polus/losses.py:21-41, y_true f32 multi-hot [rows, C]. */
+size_t polus_loss_workspace_bytes(int rows);
+int polus_softmax_xent(int dtype, const float* logits, long ldl, const int32_t* labels,
+                       const float* class_weights, float* loss, void* dlogits, long lddl,
+                       int rows, int C, void* workspace, size_t workspace_bytes, void* stream);
+int polus_sigmoid_xent(int dtype, const float* logits, long ldl, const float* y_true, long ldy,
+                       const float* class_weights, float negative_weight, float* loss,
+                       void* dlogits, long lddl, int rows, int C,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- linear-chain CRF (polus/layers.py:58-126; tensorflow-addons crf_log_likelihood /
+ * crf_decode restated).  potentials f32 [B,S,C]; tags int32 [B,S]; lengths int32 [B];
+ * trans f32 [C,C] (already masked by the caller, polus/layers.py:58-63);
+ * sample_w f32 [B] or NULL.  loss = mean_b(-ll_b * w_b).  dpot in `dtype`, dtrans f32 [C,C].
+ * C <= 16. */
+size_t polus_crf_workspace_bytes(int B, int S, int C);
+int polus_crf_nll(int dtype, const float* potentials, const int32_t* tags, const int32_t* lengths,
+                  const float* trans, const float* sample_w, float* loss, void* dpot,
+                  float* dtrans, int accumulate, int B, int S, int C,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int polus_crf_viterbi(const float* potentials, const int32_t* lengths, const float* trans,
+                      int32_t* out_tags, int B, int S, int C,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- argmax over the last axis (PolusClassifier.inference, polus/models.py:148-150) */
+int polus_argmax(const float* x, long ldx, int32_t* out, int rows, int C, void* stream);
+
+/* ---- optimizer (optimizer.apply_gradients, polus/training.py:191): Keras Adam /
+ * HF AdamWeightDecay over a flat f32 arena.  `seg` is a device table of int64 triples
+ * (begin, end, flags) covering [0,n) in chunks; flags bit0 = apply weight decay,
+ * bit1 = write a bf16 copy of the updated value to shadow[i] (GEMM weights).
+ *   p -= lr*wd*p (decayed tensors) ; m,v update ; p -= lr_t * m / (sqrt(v)+eps)
+ * g is multiplied by grad_scale and, if clip_scale != NULL, by *clip_scale (device). */
+int polus_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16,
+                    const int64_t* seg, int n_seg, int64_t n,
+                    float lr, float lr_t, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, const float* clip_scale, void* stream);
+/* sum of squares of g[0..n) -> *out (deterministic two-stage); then
+ * polus_clip_scale writes min(1, clip_norm / sqrt(*sqnorm * grad_scale^2)) */
+size_t polus_sqnorm_workspace_bytes(int64_t n);
+int polus_sqnorm(const float* g, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int polus_clip_scale(const float* sqnorm, float grad_scale, float clip_norm, float* out_scale, void* stream);
+/* f32 -> bf16 copy (shadow weights refresh after load / broadcast) and bf16/f32 casts */
+int polus_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* y = a*x elementwise, f32 (gradient averaging when the comm backend lacks AVG) */
+int polus_scale(float* x, float a, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLUS_HIP_H */

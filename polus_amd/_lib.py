@@ -1,0 +1,109 @@
+"""ctypes binding of libpolus_hip.so (include/polus_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails this
+module raises.  PyTorch is used by callers only to own device memory and streams; every
+pointer handed over here is a raw device address.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+F32, BF16 = 0, 1
+K_CONTIG, K_STRIDED = 0, 1
+ACT_NONE, ACT_GELU, ACT_SWISH, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
+GEMM_ACCUM_C, GEMM_ACT_FWD, GEMM_ACT_BWD = 1, 2, 4
+
+_c = ctypes
+_vp, _i, _l, _f, _sz, _i64 = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t, _c.c_int64
+
+# name -> (restype, argtypes); mirrors include/polus_hip.h one to one
+SIGNATURES = {
+    "polus_last_error": (_c.c_char_p, []),
+    "polus_abi_version": (_i, []),
+    "polus_device_info": (_i, [_c.POINTER(_i), _c.POINTER(_i), _c.c_char_p, _i]),
+    "polus_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "polus_gemm": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,
+                        _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "polus_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "polus_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "polus_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "polus_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_embed_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "polus_embed_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "polus_embed_ln_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "polus_colsum": (_i, [_i, _vp, _l, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "polus_loss_workspace_bytes": (_sz, [_i]),
+    "polus_softmax_xent": (_i, [_i, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _sz, _vp]),
+    "polus_sigmoid_xent": (_i, [_i, _vp, _l, _vp, _l, _vp, _f, _vp, _vp, _l, _i, _i, _vp, _sz, _vp]),
+    "polus_crf_workspace_bytes": (_sz, [_i, _i, _i]),
+    "polus_crf_nll": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_crf_viterbi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_argmax": (_i, [_vp, _l, _vp, _i, _i, _vp]),
+    "polus_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64,
+                             _f, _f, _f, _f, _f, _f, _f, _vp, _vp]),
+    "polus_sqnorm_workspace_bytes": (_sz, [_i64]),
+    "polus_sqnorm": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "polus_clip_scale": (_i, [_vp, _f, _f, _vp, _vp]),
+    "polus_cast": (_i, [_i, _vp, _i, _vp, _i64, _vp]),
+    "polus_scale": (_i, [_vp, _f, _i64, _vp]),
+}
+
+
+class PolusHipError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load():
+    """Loads (never builds) the in-tree shared library; raises if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.lib_path()
+    if not os.path.exists(path):
+        raise PolusHipError(
+            f"{path} is missing: build it with `python -m polus_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the training path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.polus_abi_version() != 1:
+        raise PolusHipError("libpolus_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().polus_last_error()
+        raise PolusHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device address of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise PolusHipError(f"unsupported dtype {torch_dtype}")

@@ -1,0 +1,78 @@
+"""Builds polus_amd/lib/libpolus_hip.so (gfx950) from polus_amd/csrc/*.hip with hipcc.
+
+In-tree on purpose: the .so travels with the repo snapshot to the GPU box; a JIT cache
+under ~/.cache would not.  hipcc cross-compiles without a GPU.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "csrc", "_obj")
+LIBNAME = "libpolus_hip.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(paths):
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(p.encode()); h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def lib_path():
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def build(force=False, verbose=True):
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "polus_hip.h")]
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        stamp = obj + ".sha"
+        dig = _digest([src] + hdrs)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+            return obj, False
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(dig)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(ch for _, ch in results)
+    out = lib_path()
+    if rebuilt or force or not os.path.exists(out):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[polus_amd.build] {out} ({'rebuilt' if rebuilt else 'up to date'})")
+    return out
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

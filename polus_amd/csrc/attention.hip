@@ -1,0 +1,441 @@
+// Fused scaled-dot-product attention for BERT (head_dim 64, S <= 512 in practice) on MFMA.
+//
+// Forward: one workgroup = 4 waves = 64 query rows of one (batch, head); each wave owns 16
+// queries and sweeps the keys in blocks of 64 with an online softmax, so the S x S scores
+// never reach HBM.  K and V blocks are staged [key][64] in LDS (row stride +32 B pad: the
+// 160-B bf16 rows are conflict-free both for ds_read_b128 row reads and for
+// ds_read_b64_tr_b16 column reads).
+//   S^T = K Q^T is computed with the KEY on the MFMA row and the query on the column
+//   (lane & 15): every lane then owns one query, its row max / row sum need two
+//   cross-lane shuffles, and the probabilities are already the B operand of O^T = V^T P^T
+//   (k = key) with no data movement: fragment element j of k-step s is key
+//   16*(2s + (j>>2)) + 4g + (j&3), and the V^T fragment is read with the same key order by
+//   the transposing LDS read.
+// Backward recomputes P from the saved log-sum-exp in two kernels, both atomics-free and
+// bitwise reproducible: dQ (same sweep as forward) and dK/dV (one workgroup per 64 keys
+// sweeping the queries, dK^T/dV^T accumulators resident in registers).
+// The additive mask is (1 - m) * -10000 exactly as polus/models.py:175-195 builds it.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 64;        // head dim
+constexpr int BLK = 64;      // rows per LDS tile / per workgroup
+constexpr float MASK_NEG = -10000.0f;
+
+template <typename T> struct TileCfg;
+template <> struct TileCfg<bf16_t> { static constexpr int RS = 160, EPC = 8, LOG_CPR = 3, NLOAD = 2; };
+template <> struct TileCfg<float> { static constexpr int RS = 288, EPC = 4, LOG_CPR = 4, NLOAD = 4; };
+
+// 64 x 64 tile: rows row0.. of a [*, ld] matrix at column offset col0 -> LDS (zero fill past nrows)
+template <typename T>
+__device__ __forceinline__ void tile_load(unsigned char* tile, const T* __restrict__ base, long ld, int row0,
+                                          int nrows, int col0, int tid) {
+    constexpr int LOG = TileCfg<T>::LOG_CPR;
+#pragma unroll
+    for (int k = 0; k < TileCfg<T>::NLOAD; ++k) {
+        int c = tid + 256 * k;
+        int r = c >> LOG, ch = c & ((1 << LOG) - 1);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nrows)
+            v = *reinterpret_cast<const uint4*>(base + (long)(row0 + r) * ld + col0 + ch * TileCfg<T>::EPC);
+        *reinterpret_cast<uint4*>(tile + r * TileCfg<T>::RS + ch * 16) = v;
+    }
+}
+
+// row fragment straight from HBM (the per-wave resident operand): 8 consecutive d of row
+template <typename T>
+__device__ __forceinline__ void frag_global(Frag<T>& f, const T* __restrict__ p, bool valid);
+template <>
+__device__ __forceinline__ void frag_global<bf16_t>(Frag<bf16_t>& f, const bf16_t* __restrict__ p, bool valid) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid) v = *reinterpret_cast<const uint4*>(p);
+    f.v = __builtin_bit_cast(bf16x8, v);
+}
+template <>
+__device__ __forceinline__ void frag_global<float>(Frag<float>& f, const float* __restrict__ p, bool valid) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (valid) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+    f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+template <typename T>
+__device__ __forceinline__ void frag_row(Frag<T>& f, const unsigned char* tile, int row, int sub, int g) {
+    frag_load_row(f, tile + row * TileCfg<T>::RS + (sub * 32 + 8 * g) * (int)sizeof(T));
+}
+
+// transposed fragment: rows = features d0..d0+15 (lane i), k = tile rows kb + 16*(j>>2) + 4g + (j&3)
+__device__ __forceinline__ void frag_tr(Frag<bf16_t>& f, const unsigned char* tile, int kb, int d0, int i, int g) {
+    const unsigned char* p = tile + (kb + 4 * g + (i >> 2)) * 160 + (d0 + 4 * (i & 3)) * 2;
+    s16x4 lo = lds_tr16(p);
+    s16x4 hi = lds_tr16(p + 16 * 160);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ void frag_tr(Frag<float>& f, const unsigned char* tile, int kb, int d0, int i, int g) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        f.v[j] = *reinterpret_cast<const float*>(tile + (kb + 16 * (j >> 2) + 4 * g + (j & 3)) * 288 + (d0 + i) * 4);
+}
+
+// accumulator tiles (2s, 2s+1) -> B-operand fragment with the key order above
+__device__ __forceinline__ void frag_from_acc(Frag<bf16_t>& f, const f32x4& t0, const f32x4& t1) {
+    f.v[0] = (bf16_t)t0[0]; f.v[1] = (bf16_t)t0[1]; f.v[2] = (bf16_t)t0[2]; f.v[3] = (bf16_t)t0[3];
+    f.v[4] = (bf16_t)t1[0]; f.v[5] = (bf16_t)t1[1]; f.v[6] = (bf16_t)t1[2]; f.v[7] = (bf16_t)t1[3];
+}
+__device__ __forceinline__ void frag_from_acc(Frag<float>& f, const f32x4& t0, const f32x4& t1) {
+    f.v[0] = t0[0]; f.v[1] = t0[1]; f.v[2] = t0[2]; f.v[3] = t0[3];
+    f.v[4] = t1[0]; f.v[5] = t1[1]; f.v[6] = t1[2]; f.v[7] = t1[3];
+}
+
+// reduce over the 4 lanes (g = 0..3) that share a column i
+__device__ __forceinline__ float col_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float col_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+template <typename T>
+__device__ __forceinline__ void store_acc_T(T* __restrict__ out, long ld, int row, int col0, const f32x4 (&o)[4],
+                                            float mul, int g, bool valid) {
+    if (!valid) return;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        float v[4] = {o[dt][0] * mul, o[dt][1] * mul, o[dt][2] * mul, o[dt][3] * mul};
+        store4<T>(out + (long)row * ld + col0 + dt * 16 + 4 * g, v);
+    }
+}
+
+struct AttnArgs {
+    const void* qkv; const int32_t* mask; void* ctx; float* lse;
+    const void* dctx; const float* delta; void* dqkv;
+    int B, S, A, H;
+    float scale;
+};
+
+__device__ __forceinline__ float key_bias(const int32_t* mask, int b, int S, int key) {
+    if (key >= S) return -INFINITY;
+    if (!mask) return 0.0f;
+    return (1.0f - (float)mask[(long)b * S + key]) * MASK_NEG;
+}
+
+// ---------------------------------------------------------------- forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + BLK * 4];
+    unsigned char* Kt = smem;
+    unsigned char* Vt = smem + BLK * TileCfg<T>::RS;
+    float* kbias = reinterpret_cast<float*>(smem + 2 * BLK * TileCfg<T>::RS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * BLK, h = blockIdx.y, b = blockIdx.z;
+    const int S = p.S, H = p.H;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const int q = q0 + wid * 16 + i;
+    const bool qvalid = q < S;
+
+    Frag<T> qf[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+        frag_global<T>(qf[sub], qkv + (long)q * ld + h * D + sub * 32 + 8 * g, qvalid);
+
+    float m = -1e30f, l = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kb0 = 0; kb0 < S; kb0 += BLK) {
+        __syncthreads();
+        tile_load<T>(Kt, qkv, ld, kb0, S, H + h * D, tid);
+        tile_load<T>(Vt, qkv, ld, kb0, S, 2 * H + h * D, tid);
+        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid);
+        __syncthreads();
+
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                Frag<T> a;
+                frag_row<T>(a, Kt, kt * 16 + i, sub, g);
+                mma16(s[kt], a, qf[sub]);  // D[key 4g+r][query i]
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] = s[kt][r] * p.scale + kbias[kt * 16 + 4 * g + r];
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = col_max(mx);
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m_new); rs += s[kt][r]; }
+        rs = col_sum(rs);
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> pb;
+            frag_from_acc(pb, s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Frag<T> va;
+                frag_tr(va, Vt, ks * 32, dt * 16, i, g);
+                mma16(o[dt], va, pb);  // D[d 4g+r][query i]
+            }
+        }
+    }
+    T* ctx = static_cast<T*>(p.ctx) + (long)b * S * H;
+    store_acc_T<T>(ctx, H, q, h * D, o, 1.0f / l, g, qvalid);
+    if (qvalid && g == 0) p.lse[((long)b * p.A + h) * S + q] = m + __logf(l);
+}
+
+// ---------------------------------------------------------------- delta = rowsum(dO * O) per head
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int S, int A, int H) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int rows = B * S;
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const int b = row / S, s = row % S;
+        for (int col = lane * 4; col < H; col += 256) {
+            float a[4], c[4];
+            load4<T>(o + (long)row * H + col, a);
+            load4<T>(dout + (long)row * H + col, c);
+            float v = a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+            // 16 consecutive lanes cover one head (64 features)
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if ((lane & 15) == 0) delta[((long)b * A + col / D) * S + s] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dQ
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + BLK * 4];
+    unsigned char* Kt = smem;
+    unsigned char* Vt = smem + BLK * TileCfg<T>::RS;
+    float* kbias = reinterpret_cast<float*>(smem + 2 * BLK * TileCfg<T>::RS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * BLK, h = blockIdx.y, b = blockIdx.z;
+    const int S = p.S, H = p.H;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const T* dctx = static_cast<const T*>(p.dctx) + (long)b * S * H;
+    const int q = q0 + wid * 16 + i;
+    const bool qvalid = q < S;
+
+    Frag<T> qf[2], dof[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        frag_global<T>(qf[sub], qkv + (long)q * ld + h * D + sub * 32 + 8 * g, qvalid);
+        frag_global<T>(dof[sub], dctx + (long)q * H + h * D + sub * 32 + 8 * g, qvalid);
+    }
+    const long stat = ((long)b * p.A + h) * S + q;
+    const float lse = qvalid ? p.lse[stat] : 0.f;
+    const float dl = qvalid ? p.delta[stat] : 0.f;
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kb0 = 0; kb0 < S; kb0 += BLK) {
+        __syncthreads();
+        tile_load<T>(Kt, qkv, ld, kb0, S, H + h * D, tid);
+        tile_load<T>(Vt, qkv, ld, kb0, S, 2 * H + h * D, tid);
+        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                Frag<T> a;
+                frag_row<T>(a, Kt, kt * 16 + i, sub, g);
+                mma16(s[kt], a, qf[sub]);
+                frag_row<T>(a, Vt, kt * 16 + i, sub, g);
+                mma16(dp[kt], a, dof[sub]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = __expf(s[kt][r] * p.scale + kbias[kt * 16 + 4 * g + r] - lse);
+                s[kt][r] = pr * (dp[kt][r] - dl) * p.scale;  // dS
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> dsb;
+            frag_from_acc(dsb, s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Frag<T> ka;
+                frag_tr(ka, Kt, ks * 32, dt * 16, i, g);
+                mma16(dq[dt], ka, dsb);  // D[d][query]
+            }
+        }
+    }
+    T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
+    store_acc_T<T>(dqkv, ld, q, h * D, dq, 1.0f, g, qvalid);
+}
+
+// ---------------------------------------------------------------- dK, dV
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + 2 * BLK * 4];
+    unsigned char* Qt = smem;
+    unsigned char* Ot = smem + BLK * TileCfg<T>::RS;
+    float* slse = reinterpret_cast<float*>(smem + 2 * BLK * TileCfg<T>::RS);
+    float* sdelta = slse + BLK;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * BLK, h = blockIdx.y, b = blockIdx.z;
+    const int S = p.S, H = p.H;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const T* dctx = static_cast<const T*>(p.dctx) + (long)b * S * H;
+    const int key = k0 + wid * 16 + i;
+    const bool kvalid = key < S;
+
+    Frag<T> kf[2], vf[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        frag_global<T>(kf[sub], qkv + (long)key * ld + H + h * D + sub * 32 + 8 * g, kvalid);
+        frag_global<T>(vf[sub], qkv + (long)key * ld + 2 * H + h * D + sub * 32 + 8 * g, kvalid);
+    }
+    const float kb = key_bias(p.mask, b, S, key);
+    const long stat0 = ((long)b * p.A + h) * S;
+
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int qb0 = 0; qb0 < S; qb0 += BLK) {
+        __syncthreads();
+        tile_load<T>(Qt, qkv, ld, qb0, S, h * D, tid);
+        tile_load<T>(Ot, dctx, H, qb0, S, h * D, tid);
+        if (tid < BLK) {
+            int qq = qb0 + tid;
+            slse[tid] = qq < S ? p.lse[stat0 + qq] : INFINITY;  // exp(-inf) = 0 for padded queries
+            sdelta[tid] = qq < S ? p.delta[stat0 + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                Frag<T> a;
+                frag_row<T>(a, Qt, qt * 16 + i, sub, g);
+                mma16(s[qt], a, kf[sub]);   // D[query 4g+r][key i]
+                frag_row<T>(a, Ot, qt * 16 + i, sub, g);
+                mma16(dp[qt], a, vf[sub]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ql = qt * 16 + 4 * g + r;
+                float pr = __expf(s[qt][r] * p.scale + kb - slse[ql]);
+                dp[qt][r] = pr * (dp[qt][r] - sdelta[ql]) * p.scale;  // dS
+                s[qt][r] = pr;                                         // P
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> pb, dsb;
+            frag_from_acc(pb, s[2 * ks], s[2 * ks + 1]);
+            frag_from_acc(dsb, dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Frag<T> a;
+                frag_tr(a, Ot, ks * 32, dt * 16, i, g);
+                mma16(dv[dt], a, pb);   // dV^T[d][key] += dO^T P
+                frag_tr(a, Qt, ks * 32, dt * 16, i, g);
+                mma16(dk[dt], a, dsb);  // dK^T[d][key] += Q^T dS
+            }
+        }
+    }
+    T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
+    store_acc_T<T>(dqkv, ld, key, H + h * D, dk, 1.0f, g, kvalid);
+    store_acc_T<T>(dqkv, ld, key, 2 * H + h * D, dv, 1.0f, g, kvalid);
+}
+
+int check_common(const char* who, int dtype, int B, int S, int A, int hd) {
+    POLUS_REQUIRE(dtype == POLUS_F32 || dtype == POLUS_BF16, "%s: bad dtype %d", who, dtype);
+    POLUS_REQUIRE(hd == D, "%s: head_dim must be 64 (got %d)", who, hd);
+    POLUS_REQUIRE(B > 0 && S > 0 && A > 0, "%s: bad shape B=%d S=%d A=%d", who, B, S, A);
+    POLUS_REQUIRE(B <= 65535 && A <= 65535, "%s: B and n_heads must be <= 65535", who);
+    return POLUS_OK;
+}
+
+}  // namespace
+
+extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* mask, void* ctx, float* lse,
+                                   int B, int S, int n_heads, int head_dim, void* stream) {
+    int rc = check_common("polus_attention_fwd", dtype, B, S, n_heads, head_dim);
+    if (rc) return rc;
+    POLUS_REQUIRE(qkv && ctx && lse, "polus_attention_fwd: null pointer");
+    POLUS_REQUIRE(polus_aligned16(qkv) && polus_aligned16(ctx), "polus_attention_fwd: pointers must be 16-byte aligned");
+    AttnArgs a = {};
+    a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.lse = lse;
+    a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
+    dim3 grid((S + BLK - 1) / BLK, n_heads, B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == POLUS_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, st, a);
+    POLUS_CHECK_LAUNCH("polus_attention_fwd");
+    return POLUS_OK;
+}
+
+extern "C" size_t polus_attention_bwd_workspace_bytes(int B, int S, int n_heads) {
+    return (size_t)B * S * n_heads * sizeof(float);
+}
+
+extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* mask, const void* ctx,
+                                   const void* dctx, const float* lse, void* dqkv,
+                                   int B, int S, int n_heads, int head_dim,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("polus_attention_bwd", dtype, B, S, n_heads, head_dim);
+    if (rc) return rc;
+    POLUS_REQUIRE(qkv && ctx && dctx && lse && dqkv, "polus_attention_bwd: null pointer");
+    POLUS_REQUIRE(polus_aligned16(qkv) && polus_aligned16(ctx) && polus_aligned16(dctx) && polus_aligned16(dqkv),
+                  "polus_attention_bwd: pointers must be 16-byte aligned");
+    size_t need = polus_attention_bwd_workspace_bytes(B, S, n_heads);
+    if (!workspace || workspace_bytes < need) { polus_set_error("polus_attention_bwd: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
+    AttnArgs a = {};
+    a.qkv = qkv; a.mask = mask; a.lse = const_cast<float*>(lse); a.dctx = dctx; a.dqkv = dqkv;
+    a.delta = static_cast<const float*>(workspace);
+    a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rows = B * S, dblocks = (rows + 3) / 4;
+    if (dblocks > 4096) dblocks = 4096;
+    dim3 grid((S + BLK - 1) / BLK, n_heads, B);
+    if (dtype == POLUS_BF16) {
+        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(dblocks), dim3(256), 0, st, (const bf16_t*)ctx, (const bf16_t*)dctx, static_cast<float*>(workspace), B, S, n_heads, a.H);
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(delta)");
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dblocks), dim3(256), 0, st, (const float*)ctx, (const float*)dctx, static_cast<float*>(workspace), B, S, n_heads, a.H);
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(delta)");
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, st, a);
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), 0, st, a);
+    }
+    POLUS_CHECK_LAUNCH("polus_attention_bwd(dkv)");
+    return POLUS_OK;
+}

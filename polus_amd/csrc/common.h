@@ -1,0 +1,130 @@
+// Shared device/host helpers for the Polus MI355X (gfx950) kernel library.
+// Wave = 64 lanes everywhere; MFMA shape 16x16 (bf16: K=32, f32: K=4 x 8 issues).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/polus_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- error plumbing (host)
+void polus_set_error(const char* fmt, ...);
+#define POLUS_FAIL(...) do { polus_set_error(__VA_ARGS__); return POLUS_ERR_INVALID; } while (0)
+#define POLUS_REQUIRE(cond, ...) do { if (!(cond)) { polus_set_error(__VA_ARGS__); return POLUS_ERR_INVALID; } } while (0)
+#define POLUS_CHECK_LAUNCH(name) do { hipError_t e__ = hipGetLastError(); \
+    if (e__ != hipSuccess) { polus_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); return POLUS_ERR_HIP; } } while (0)
+#define POLUS_HIP(call) do { hipError_t e__ = (call); \
+    if (e__ != hipSuccess) { polus_set_error("%s failed: %s", #call, hipGetErrorString(e__)); return POLUS_ERR_HIP; } } while (0)
+
+static inline size_t polus_dtype_size(int dt) { return dt == POLUS_BF16 ? 2 : 4; }
+static inline bool polus_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---------------------------------------------------------------- scalar conversions
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return (bf16_t)x; }
+
+// 4-element vector load/store of T as floats (bf16: 8 B, f32: 16 B)
+template <typename T> __device__ __forceinline__ void load4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    bf16x4 t; t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float swish_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish_grad_f(float x) {
+    float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float apply_act(int act, float x) {
+    return act == POLUS_ACT_GELU ? gelu_f(x) : act == POLUS_ACT_SWISH ? swish_f(x)
+         : act == POLUS_ACT_RELU ? fmaxf(x, 0.0f) : act == POLUS_ACT_TANH ? tanhf(x) : x;
+}
+// derivative given the pre-activation u
+__device__ __forceinline__ float apply_act_grad(int act, float u) {
+    if (act == POLUS_ACT_GELU) return gelu_grad_f(u);
+    if (act == POLUS_ACT_SWISH) return swish_grad_f(u);
+    if (act == POLUS_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
+    if (act == POLUS_ACT_TANH) { float t = tanhf(u); return 1.0f - t * t; }
+    return 1.0f;
+}
+
+// ---------------------------------------------------------------- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- MFMA fragments
+// A "fragment" is the 8 contraction elements k = 8*g + j (j = 0..7) that lane
+// (i = lane & 15, g = lane >> 4) holds for tile row/column i.  bf16: one
+// v_mfma_f32_16x16x32_bf16; f32: eight v_mfma_f32_16x16x4_f32, issue j taking element j
+// (its k' = g maps to k = 8g + j, so all 32 k are covered once).  The f32 form is an
+// exact k-ordered fmaf chain: deterministic and bit-stable.
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+// D[row = 4g + r][col = i] += sum_k A[row][k] * B[k][col]; `a` supplies rows, `b` columns.
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// Row-read fragment: 8 consecutive k of one tile row, K contiguous at `p` (16-B aligned).
+__device__ __forceinline__ void frag_load_row(Frag<bf16_t>& f, const unsigned char* p) {
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+}
+__device__ __forceinline__ void frag_load_row(Frag<float>& f, const unsigned char* p) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    float4 b = *reinterpret_cast<const float4*>(p + 16);
+    f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+    f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+
+// Transposed-read of 4 k-rows x 16 columns of bf16 (ds_read_b64_tr_b16).  Lane i of each
+// 16-lane group passes the address of (k-row i>>2, columns 4*(i&3)..+3) and receives
+// column i of the four k-rows.  EXEC must be all ones.
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}

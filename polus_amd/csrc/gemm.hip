@@ -1,0 +1,390 @@
+// MFMA GEMM for the Dense layers of the BERT step and their gradients (gfx950).
+//
+// One 256-thread workgroup (4 waves, 2x2) computes a 128x128 tile of C; each wave owns
+// 64x64 = 4x4 MFMA 16x16 tiles (64 accumulator registers).  A K-step is 128 bytes of K per
+// row (64 bf16 / 32 f32).  Operands are staged HBM -> registers -> LDS (double-buffered,
+// one barrier per K-step, the next tile's global loads in flight under the MFMAs).
+//
+// LDS images:
+//   K-contiguous operand ([rows][K] in memory): [128 rows][128 B + 32 B pad] = 160-B rows;
+//     fragments are ds_read_b128 of (row i, 16 B at k-group g) — 160 B puts the 16 rows of a
+//     b128 lane group on 16 distinct 16-B slots.
+//   K-strided operand ([K][rows] in memory: dY and X in dW = dY^T X, W in dX = dY W):
+//     kept k-major exactly as loaded (coalesced 16-B chunks along the row index), bf16 rows
+//     of 288 B with byte-bit-7 XOR for odd k-octets, f32 rows of 512 B with bit-6 XOR;
+//     bf16 fragments come out of ds_read_b64_tr_b16 (hardware transpose), f32 ones from
+//     ds_read_b32.
+// The MFMA is issued as D[n][m] (B rows as the A operand) so that a lane ends up with four
+// consecutive n of one output row: 8/16-byte epilogue accesses.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int KC_STRIDE = 160;
+constexpr int OPERAND_BYTES = 128 * KC_STRIDE;  // 20480, >= every K-strided image
+constexpr int SMEM_BYTES = 4 * OPERAND_BYTES;   // A0 B0 A1 B1
+
+template <typename T> struct Cfg;
+template <> struct Cfg<bf16_t> {
+    static constexpr int BK = 64, EPC = 8, NSUB = 2;
+    static constexpr int KS_STRIDE = 288, KS_SWZ = 7, LOG_RCH = 4;
+};
+template <> struct Cfg<float> {
+    static constexpr int BK = 32, EPC = 4, NSUB = 1;
+    static constexpr int KS_STRIDE = 512, KS_SWZ = 6, LOG_RCH = 5;
+};
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    long lda, ldb, ldc;
+    int M, N, K;
+    int k_per_split;  // multiple of BK
+    float alpha;
+    const float* bias;
+    const void* resid; long ldr;
+    void* aux; long ldaux;
+    int act, flags;
+    float* partial;  // split-K slabs [splits][M][N] or null
+    int a_vec, b_vec, epi_vec;
+};
+
+template <typename T> union Chunk { uint4 u; T e[16 / sizeof(T)]; };
+
+// ---- HBM -> registers: one operand tile = 1024 16-byte chunks, 4 per thread
+template <typename T>
+__device__ __forceinline__ void gload_kc(uint4 (&r)[4], const T* __restrict__ base, long ld, int rows,
+                                         int r0, int k0, int kend, int vec, int tid) {
+    constexpr int EPC = Cfg<T>::EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + NTHREADS * i;
+        int gr = r0 + (c >> 3), gk = k0 + (c & 7) * EPC;
+        Chunk<T> v; v.u = make_uint4(0, 0, 0, 0);
+        if (gr < rows && gk < kend) {
+            const T* p = base + (long)gr * ld + gk;
+            if (vec && gk + EPC <= kend) v.u = *reinterpret_cast<const uint4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) if (gk + e < kend) v.e[e] = p[e];
+            }
+        }
+        r[i] = v.u;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void sstore_kc(unsigned char* tile, const uint4 (&r)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + NTHREADS * i;
+        *reinterpret_cast<uint4*>(tile + (c >> 3) * KC_STRIDE + (c & 7) * 16) = r[i];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void gload_ks(uint4 (&r)[4], const T* __restrict__ base, long ld, int rows,
+                                         int r0, int k0, int kend, int vec, int tid) {
+    constexpr int EPC = Cfg<T>::EPC, LOG = Cfg<T>::LOG_RCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + NTHREADS * i;
+        int gk = k0 + (c >> LOG), gr = r0 + (c & ((1 << LOG) - 1)) * EPC;
+        Chunk<T> v; v.u = make_uint4(0, 0, 0, 0);
+        if (gk < kend && gr < rows) {
+            const T* p = base + (long)gk * ld + gr;
+            if (vec && gr + EPC <= rows) v.u = *reinterpret_cast<const uint4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) if (gr + e < rows) v.e[e] = p[e];
+            }
+        }
+        r[i] = v.u;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void sstore_ks(unsigned char* tile, const uint4 (&r)[4], int tid) {
+    constexpr int LOG = Cfg<T>::LOG_RCH;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = tid + NTHREADS * i;
+        int krow = c >> LOG, rc = c & ((1 << LOG) - 1);
+        int off = krow * Cfg<T>::KS_STRIDE + ((rc * 16) ^ (((krow >> 3) & 1) << Cfg<T>::KS_SWZ));
+        *reinterpret_cast<uint4*>(tile + off) = r[i];
+    }
+}
+
+// ---- LDS -> fragments
+// K-contiguous image: tile row `row`, k-substep `sub`, lane group g
+template <typename T>
+__device__ __forceinline__ void frag_kc(Frag<T>& f, const unsigned char* tile, int row, int sub, int g) {
+    frag_load_row(f, tile + row * KC_STRIDE + sub * (32 * (int)sizeof(T)) + g * (8 * (int)sizeof(T)));
+}
+// K-strided image: rows col0..col0+15 of the operand, k = sub*32 + 8g + j
+__device__ __forceinline__ void frag_ks(Frag<bf16_t>& f, const unsigned char* tile, int col0, int sub, int i, int g) {
+    int kb = sub * 32 + 8 * g + (i >> 2);
+    int cb = (col0 + 4 * (i & 3)) * 2;
+    int swz = (g & 1) << 7;  // ((k >> 3) & 1) for k = sub*32 + 8g + (0..7)
+    s16x4 lo = lds_tr16(tile + kb * 288 + (cb ^ swz));
+    s16x4 hi = lds_tr16(tile + (kb + 4) * 288 + (cb ^ swz));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ void frag_ks(Frag<float>& f, const unsigned char* tile, int col0, int sub, int i, int g) {
+    int cb = ((col0 + i) * 4) ^ ((g & 1) << 6);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        f.v[j] = *reinterpret_cast<const float*>(tile + (8 * g + j) * 512 + cb);
+}
+
+template <typename TC> __device__ __forceinline__ void ld4x(const TC* p, float (&v)[4], int vec, int nvalid) {
+    if (vec && nvalid >= 4) load4<TC>(p, v);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = r < nvalid ? to_f<TC>(p[r]) : 0.0f;
+    }
+}
+template <typename TC> __device__ __forceinline__ void st4x(TC* p, const float (&v)[4], int vec, int nvalid) {
+    if (vec && nvalid >= 4) store4<TC>(p, v);
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nvalid) p[r] = from_f<TC>(v[r]);
+    }
+}
+
+template <typename T, bool A_KS, bool B_KS, typename TC>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BK = Cfg<T>::BK, NSUB = Cfg<T>::NSUB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each
+    // XCD a contiguous run of tiles so neighbours reuse the same A row panel.
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x, nwg = gridDim.x;
+    int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    const T* A = static_cast<const T*>(p.A);
+    const T* B = static_cast<const T*>(p.B);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+        if (A_KS) gload_ks<T>(ra, A, p.lda, p.M, m0, k0, kend, p.a_vec, tid);
+        else      gload_kc<T>(ra, A, p.lda, p.M, m0, k0, kend, p.a_vec, tid);
+        if (B_KS) gload_ks<T>(rb, B, p.ldb, p.N, n0, k0, kend, p.b_vec, tid);
+        else      gload_kc<T>(rb, B, p.ldb, p.N, n0, k0, kend, p.b_vec, tid);
+    };
+    auto sstore = [&](int buf) {
+        unsigned char* ta = smem + buf * 2 * OPERAND_BYTES;
+        unsigned char* tb = ta + OPERAND_BYTES;
+        if (A_KS) sstore_ks<T>(ta, ra, tid); else sstore_kc<T>(ta, ra, tid);
+        if (B_KS) sstore_ks<T>(tb, rb, tid); else sstore_kc<T>(tb, rb, tid);
+    };
+
+    if (nk > 0) { gload(kbeg); sstore(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+        const unsigned char* ta = smem + cur * 2 * OPERAND_BYTES;
+        const unsigned char* tb = ta + OPERAND_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            Frag<T> af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (A_KS) frag_ks(af[t], ta, wm * 64 + t * 16, sub, i, g);
+                else      frag_kc<T>(af[t], ta, wm * 64 + t * 16 + i, sub, g);
+                if (B_KS) frag_ks(bf[t], tb, wn * 64 + t * 16, sub, i, g);
+                else      frag_kc<T>(bf[t], tb, wn * 64 + t * 16 + i, sub, g);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) mma16(acc[tm][tn], bf[tn], af[tm]);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = tile row i, n = 4g + r
+    const int ev = p.epi_vec;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int n = n0 + wn * 64 + tn * 16 + 4 * g;
+            const int nvalid = p.N - n;
+            if (nvalid <= 0) continue;
+            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
+            if (p.partial) {
+                float* dst = p.partial + ((long)blockIdx.z * p.M + m) * p.N + n;
+                st4x<float>(dst, v, (p.N & 3) == 0, nvalid);
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+            if (p.bias) {
+                float b[4]; ld4x<float>(p.bias + n, b, ev, nvalid);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b[r];
+            }
+            if (p.flags & POLUS_GEMM_ACT_FWD) {
+                if (p.aux) st4x<T>(static_cast<T*>(p.aux) + (long)m * p.ldaux + n, v, ev, nvalid);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+            }
+            if (p.flags & POLUS_GEMM_ACT_BWD) {
+                float u[4]; ld4x<T>(static_cast<const T*>(p.aux) + (long)m * p.ldaux + n, u, ev, nvalid);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= apply_act_grad(p.act, u[r]);
+            }
+            if (p.resid) {
+                float rr[4]; ld4x<T>(static_cast<const T*>(p.resid) + (long)m * p.ldr + n, rr, ev, nvalid);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+            TC* c = static_cast<TC*>(p.C) + (long)m * p.ldc + n;
+            if (p.flags & POLUS_GEMM_ACCUM_C) {
+                float o[4]; ld4x<TC>(c, o, ev, nvalid);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+            st4x<TC>(c, v, ev, nvalid);
+        }
+    }
+}
+
+// order-fixed split-K reduction: C = alpha * sum_z slab[z] (+ bias) (+ C)
+template <typename TC>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, int M, int N,
+                                     TC* C, long ldc, float alpha, const float* bias, int accum) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)M * N;
+    if (idx >= total) return;
+    int m = idx / N, n = idx % N;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(long)z * total + idx];
+    s *= alpha;
+    if (bias) s += bias[n];
+    TC* c = C + (long)m * ldc + n;
+    if (accum) s += to_f<TC>(*c);
+    *c = from_f<TC>(s);
+}
+
+template <typename T, bool A_KS, bool B_KS, typename TC>
+int launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;  // per instantiation
+    auto kern = gemm_kernel<T, A_KS, B_KS, TC>;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SMEM_BYTES, st, a);
+    POLUS_CHECK_LAUNCH("polus_gemm");
+    return POLUS_OK;
+}
+
+template <typename T, typename TC>
+int dispatch_layout(int al, int bl, const GemmArgs& a, dim3 grid, hipStream_t st) {
+    if (al == POLUS_K_CONTIG && bl == POLUS_K_CONTIG) return launch<T, false, false, TC>(a, grid, st);
+    if (al == POLUS_K_CONTIG && bl == POLUS_K_STRIDED) return launch<T, false, true, TC>(a, grid, st);
+    if (al == POLUS_K_STRIDED && bl == POLUS_K_STRIDED) return launch<T, true, true, TC>(a, grid, st);
+    return launch<T, true, false, TC>(a, grid, st);
+}
+
+}  // namespace
+
+extern "C" size_t polus_gemm_workspace_bytes(int M, int N, int split_k) {
+    if (split_k <= 1) return 0;
+    return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
+                          const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                          int M, int N, int K, float alpha,
+                          const float* bias, const void* resid, long ldr, void* aux, long ldaux,
+                          int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    POLUS_REQUIRE(dtype == POLUS_F32 || dtype == POLUS_BF16, "polus_gemm: bad dtype %d", dtype);
+    POLUS_REQUIRE(c_dtype == POLUS_F32 || c_dtype == dtype, "polus_gemm: c_dtype must be f32 or dtype");
+    POLUS_REQUIRE(M > 0 && N > 0 && K > 0, "polus_gemm: empty problem M=%d N=%d K=%d", M, N, K);
+    POLUS_REQUIRE(A && B && C, "polus_gemm: null operand");
+    POLUS_REQUIRE((a_layout | 1) == 1 && (b_layout | 1) == 1, "polus_gemm: bad layout");
+    POLUS_REQUIRE(lda >= (a_layout == POLUS_K_CONTIG ? K : M), "polus_gemm: lda %ld too small", lda);
+    POLUS_REQUIRE(ldb >= (b_layout == POLUS_K_CONTIG ? K : N), "polus_gemm: ldb %ld too small", ldb);
+    POLUS_REQUIRE(ldc >= N, "polus_gemm: ldc %ld < N %d", ldc, N);
+    POLUS_REQUIRE(!resid || ldr >= N, "polus_gemm: ldr too small");
+    POLUS_REQUIRE(!((flags & POLUS_GEMM_ACT_BWD) && !aux), "polus_gemm: ACT_BWD needs aux");
+    POLUS_REQUIRE(!aux || ldaux >= N, "polus_gemm: ldaux too small");
+    if (split_k < 1) split_k = 1;
+    const size_t es = polus_dtype_size(dtype), ecs = polus_dtype_size(c_dtype);
+    const int bk = dtype == POLUS_BF16 ? 64 : 32;
+    int nkt = (K + bk - 1) / bk;
+    if (split_k > nkt) split_k = nkt;
+    if (split_k > 1) {
+        POLUS_REQUIRE(!resid && !aux && !(flags & (POLUS_GEMM_ACT_FWD | POLUS_GEMM_ACT_BWD)),
+                      "polus_gemm: split_k supports only bias / ACCUM_C epilogues");
+        if (!workspace || workspace_bytes < polus_gemm_workspace_bytes(M, N, split_k)) {
+            polus_set_error("polus_gemm: workspace %zu < %zu", workspace_bytes, polus_gemm_workspace_bytes(M, N, split_k));
+            return POLUS_ERR_WORKSPACE;
+        }
+    }
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.M = M; a.N = N; a.K = K; a.alpha = alpha;
+    a.k_per_split = ((nkt + split_k - 1) / split_k) * bk;
+    a.bias = bias; a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = ldaux;
+    a.act = act; a.flags = flags;
+    a.partial = split_k > 1 ? static_cast<float*>(workspace) : nullptr;
+    a.a_vec = polus_aligned16(A) && ((lda * es) % 16 == 0);
+    a.b_vec = polus_aligned16(B) && ((ldb * es) % 16 == 0);
+    // 4-wide epilogue accesses: every touched row start must be 4-element aligned
+    bool ev = (((uintptr_t)C) % (4 * ecs) == 0) && (ldc % 4 == 0);
+    if (bias) ev = ev && (((uintptr_t)bias) % 16 == 0);
+    if (resid) ev = ev && (((uintptr_t)resid) % (4 * es) == 0) && (ldr % 4 == 0);
+    if (aux) ev = ev && (((uintptr_t)aux) % (4 * es) == 0) && (ldaux % 4 == 0);
+    a.epi_vec = ev;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
+    dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc;
+    if (dtype == POLUS_BF16) {
+        rc = (c_dtype == POLUS_F32) ? dispatch_layout<bf16_t, float>(a_layout, b_layout, a, grid, st)
+                                    : dispatch_layout<bf16_t, bf16_t>(a_layout, b_layout, a, grid, st);
+    } else {
+        rc = dispatch_layout<float, float>(a_layout, b_layout, a, grid, st);
+    }
+    if (rc != POLUS_OK) return rc;
+    if (split_k > 1) {
+        long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (c_dtype == POLUS_F32)
+            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st,
+                               a.partial, splits_eff, M, N, static_cast<float*>(C), ldc, alpha, bias,
+                               (flags & POLUS_GEMM_ACCUM_C) ? 1 : 0);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st,
+                               a.partial, splits_eff, M, N, static_cast<bf16_t*>(C), ldc, alpha, bias,
+                               (flags & POLUS_GEMM_ACCUM_C) ? 1 : 0);
+        POLUS_CHECK_LAUNCH("polus_gemm(splitk_reduce)");
+    }
+    return POLUS_OK;
+}

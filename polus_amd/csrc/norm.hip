@@ -1,0 +1,564 @@
+// LayerNorm fwd/bwd, embedding gather+LN fwd/bwd and deterministic column sums (gfx950).
+// All HBM-bound: one wave64 owns one row, lanes read 4 consecutive features per chunk
+// (8-B bf16 / 16-B f32 accesses, 512 B / 1 KiB per wave-instruction), row statistics by
+// wave reductions, cross-row (per-feature) sums accumulated in registers over a
+// grid-stride row loop and finished by an order-fixed two-stage reduction (no atomics,
+// bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 8;           // chunks of 256 features per row: H <= 2048 (template NC <= MAXC)
+constexpr int WAVES = 4;          // waves per workgroup
+constexpr int MAX_PARTIAL_BLOCKS = 1024;
+
+__device__ __forceinline__ int n_chunks(int H) { return (H + 255) >> 8; }
+
+template <typename T, int NC>
+__device__ __forceinline__ void load_row(const T* row, int H, int lane, float (&v)[NC][4]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) load4<T>(row + col, v[c]);
+        else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+    }
+}
+
+// mean / rstd of one row held in registers (two-pass, biased variance)
+template <int NC>
+__device__ __forceinline__ void row_stats(const float (&v)[NC][4], int H, int lane, float eps,
+                                          float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[c][e] - mean; q += d * d; }
+        }
+    }
+    float var = wave_sum(q) / (float)H;
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+template <typename T, int NC>
+__device__ __forceinline__ void normalize_store(const float (&v)[NC][4], const float* gamma, const float* beta,
+                                                T* y, int H, int lane, float mean, float rstd) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) {
+            float g[4], b[4], o[4];
+            load4<float>(gamma + col, g);
+            load4<float>(beta + col, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+            store4<T>(y + col, o);
+        }
+    }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+        float v[NC][4];
+        load_row<T, NC>(x + (long)row * H, H, lane, v);
+        float mu, rs;
+        row_stats<NC>(v, H, lane, eps, mu, rs);
+        normalize_store<T, NC>(v, gamma, beta, y + (long)row * H, H, lane, mu, rs);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// Shared tail of the LN backward kernels: given x-hat pieces and dy for one row, produce dx
+// and accumulate the per-feature sums.
+template <int NC> struct ColAcc { float dg[NC][4], db[NC][4], dbias[NC][4]; };
+
+template <int NC>
+__device__ __forceinline__ void colacc_zero(ColAcc<NC>& a) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a.dg[c][e] = a.db[c][e] = a.dbias[c][e] = 0.f;
+}
+
+// block-level, order-fixed combine of the 4 waves' column accumulators into
+// partial[block][3][H]
+template <int NC>
+__device__ __forceinline__ void colacc_flush(const ColAcc<NC>& a, float* lds /*[3*H]*/, float* partial, int H,
+                                             int lane, int wid, int want_bias) {
+    for (int w = 0; w < WAVES; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                int col = (lane + 64 * c) * 4;
+                if (col < H) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (w == 0) {
+                            lds[col + e] = a.dg[c][e]; lds[H + col + e] = a.db[c][e]; lds[2 * H + col + e] = a.dbias[c][e];
+                        } else {
+                            lds[col + e] += a.dg[c][e]; lds[H + col + e] += a.db[c][e]; lds[2 * H + col + e] += a.dbias[c][e];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* dst = partial + (long)blockIdx.x * 3 * H;
+    int n = (want_bias ? 3 : 2) * H;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) dst[idx] = lds[idx];
+}
+
+template <typename T, typename TDX, int NC>
+__device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dyrow, const float* gamma,
+                                           TDX* dxrow, int H, int lane, float mu, float rs, ColAcc<NC>& acc,
+                                           int want_bias) {
+    float dy[NC][4];
+    load_row<T, NC>(dyrow, H, lane, dy);
+    float s1 = 0.f, s2 = 0.f;
+    float xh[NC][4], dxh[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) {
+            float g[4];
+            load4<float>(gamma + col, g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[c][e] = (xv[c][e] - mu) * rs;
+                dxh[c][e] = dy[c][e] * g[e];
+                s1 += dxh[c][e];
+                s2 += dxh[c][e] * xh[c][e];
+                acc.dg[c][e] += dy[c][e] * xh[c][e];
+                acc.db[c][e] += dy[c][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xh[c][e] = dxh[c][e] = 0.f;
+        }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (dxh[c][e] - s1 - xh[c][e] * s2) * rs;
+                if (want_bias) acc.dbias[c][e] += o[e];
+            }
+            store4<TDX>(dxrow + col, o);
+        }
+    }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx,
+                                                     float* __restrict__ partial, int rows, int H, int want_bias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    ColAcc<NC> acc;
+    colacc_zero(acc);
+    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+        float xv[NC][4];
+        load_row<T, NC>(x + (long)row * H, H, lane, xv);
+        ln_bwd_row<T, T, NC>(xv, dy + (long)row * H, gamma, dx + (long)row * H, H, lane, mean[row], rstd[row], acc, want_bias);
+    }
+    colacc_flush(acc, lds, partial, H, lane, wid, want_bias);
+}
+
+// out_k[c] (+)= sum_p partial[p][k*seg + c]: 64 columns x 16 partial groups per block,
+// groups combined in fixed order.
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int P, int pstride,
+                                                               int ncols, int seg, float* out0, float* out1,
+                                                               float* out2, int accumulate) {
+    __shared__ float red[16][64];
+    const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (col < ncols)
+        for (int p = gy; p < P; p += 16) s += partial[(long)p * pstride + col];
+    red[gy][cx] = s;
+    __syncthreads();
+    if (gy == 0 && col < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cx];
+        int which = col / seg, c = col % seg;
+        float* out = which == 0 ? out0 : which == 1 ? out1 : out2;
+        if (out) out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// ---- generic column sums: grid (col tiles of 1024, row chunks); thread owns 4 columns
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long ldx, int rows, int cols,
+                                                             int rows_per_chunk, float* __restrict__ partial,
+                                                             const int32_t* __restrict__ sel, int sel_value, int vec) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < cols) {
+        const int nv = cols - col;
+        for (int r = r0; r < r1; ++r) {
+            if (sel && sel[r] != sel_value) continue;
+            float v[4];
+            const T* p = x + (long)r * ldx + col;
+            if (vec && nv >= 4) load4<T>(p, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < nv ? to_f<T>(p[e]) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nv) partial[(long)blockIdx.y * cols + col + e] = a[e];
+    }
+}
+
+int colsum_launch(int dtype, const void* x, long ldx, int rows, int cols, float* out, int accumulate,
+                  const int32_t* sel, int sel_value, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    int chunks = (rows + 63) / 64;
+    if (chunks > 256) chunks = 256;
+    int rpc = (rows + chunks - 1) / chunks;
+    chunks = (rows + rpc - 1) / rpc;
+    size_t need = (size_t)chunks * cols * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        polus_set_error("polus_colsum: workspace %zu < %zu", workspace_bytes, need);
+        return POLUS_ERR_WORKSPACE;
+    }
+    float* partial = static_cast<float*>(workspace);
+    dim3 grid((cols + 1023) / 1024, chunks);
+    size_t es = polus_dtype_size(dtype);
+    int vec = (((uintptr_t)x) % (4 * es) == 0) && (ldx % 4 == 0);
+    if (dtype == POLUS_BF16)
+        hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, rows, cols, rpc, partial, sel, sel_value, vec);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, rows, cols, rpc, partial, sel, sel_value, vec);
+    POLUS_CHECK_LAUNCH("polus_colsum(partial)");
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st,
+                       partial, chunks, cols, cols, cols, out, (float*)nullptr, (float*)nullptr, accumulate);
+    POLUS_CHECK_LAUNCH("polus_colsum(finalize)");
+    return POLUS_OK;
+}
+
+// pick the smallest instantiated chunk count covering H
+#define POLUS_NC_DISPATCH(H, T, KERNEL, ...)                                                   \
+    do {                                                                                       \
+        int nc__ = ((H) + 255) / 256;                                                          \
+        if (nc__ <= 1) hipLaunchKernelGGL((KERNEL<T, 1>), __VA_ARGS__);                        \
+        else if (nc__ <= 2) hipLaunchKernelGGL((KERNEL<T, 2>), __VA_ARGS__);                   \
+        else if (nc__ <= 3) hipLaunchKernelGGL((KERNEL<T, 3>), __VA_ARGS__);                   \
+        else if (nc__ <= 4) hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                  \
+    } while (0)
+
+int ln_blocks(int rows) {
+    int b = (rows + WAVES - 1) / WAVES;
+    return b > MAX_PARTIAL_BLOCKS ? MAX_PARTIAL_BLOCKS : (b < 1 ? 1 : b);
+}
+
+// ---------------------------------------------------------------- embeddings
+template <typename T, int NC>
+__device__ __forceinline__ void gather_sum(const float* word, const float* pos, const float* type, int id, int s,
+                                           int tt, int H, int lane, float (&v)[NC][4]) {
+    const float* w = word + (long)id * H;
+    const float* p = pos + (long)s * H;
+    const float* t = type + (long)tt * H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) {
+            float a[4], b[4], d[4];
+            load4<float>(w + col, a); load4<float>(p + col, b); load4<float>(t + col, d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[c][e] = (a[e] + d[e]) + b[e];  // word + type + pos (oracle order)
+        } else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+    }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tts,
+                                                        const float* __restrict__ word, const float* __restrict__ pos,
+                                                        const float* __restrict__ type, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y,
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        int B, int S, int H, int vocab, int type_vocab, float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int rows = B * S;
+    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+        int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        int tt = tts ? tts[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+        float v[NC][4];
+        gather_sum<T, NC>(word, pos, type, id, row % S, tt, H, lane, v);
+        float mu, rs;
+        row_stats<NC>(v, H, lane, eps, mu, rs);
+        normalize_store<T, NC>(v, gamma, beta, y + (long)row * H, H, lane, mu, rs);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// LN backward of the embedding sum: de (f32 workspace) + gamma/beta partials
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void embed_bwd_ln_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
+                                                           const int32_t* __restrict__ tts, const float* __restrict__ word,
+                                                           const float* __restrict__ pos, const float* __restrict__ type,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ de,
+                                                           float* __restrict__ partial, int B, int S, int H, int vocab,
+                                                           int type_vocab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int rows = B * S;
+    ColAcc<NC> acc;
+    colacc_zero(acc);
+    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+        int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        int tt = tts ? tts[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
+        float xv[NC][4];
+        gather_sum<T, NC>(word, pos, type, id, row % S, tt, H, lane, xv);
+        ln_bwd_row<T, float, NC>(xv, dy + (long)row * H, gamma, de + (long)row * H, H, lane, mean[row], rstd[row], acc, 0);
+    }
+    colacc_flush(acc, lds, partial, H, lane, wid, 0);
+}
+
+// word-table gradient, atomic form: one wave per token, 256 contiguous bytes per
+// wave-instruction (the shape global f32 atomics run at full rate for)
+__global__ __launch_bounds__(256) void embed_scatter_atomic_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
+                                                                   float* __restrict__ gword, int rows, int H, int vocab) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+        int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const float* src = de + (long)row * H;
+        float* dst = gword + (long)id * H;
+        for (int col = lane; col < H; col += 64) atomicAdd(dst + col, src[col]);
+    }
+}
+
+// word-table gradient, reproducible form: the first occurrence of an id owns it and adds
+// the rows of every occurrence in token order.
+__global__ __launch_bounds__(256) void embed_scatter_owner_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
+                                                                  float* __restrict__ gword, int rows, int H, int vocab) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+        const int id = ids[row];
+        bool dup = false;
+        for (int j0 = 0; j0 < row && !dup; j0 += 64) {
+            int j = j0 + lane;
+            bool hit = (j < row) && (ids[j] == id);
+            dup = __any(hit);
+        }
+        if (dup) continue;  // wave-uniform
+        int cid = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        float* dst = gword + (long)cid * H;
+        for (int c0 = 0; c0 < H; c0 += 64 * 4) {  // 256-feature slabs held in registers
+            int col = c0 + lane * 4;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j0 = row; j0 < rows; j0 += 64) {
+                int j = j0 + lane;
+                unsigned long long m = __ballot((j < rows) && (ids[j] == id));
+                while (m) {
+                    int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (col < H) {
+                        float v[4];
+                        load4<float>(de + (long)(j0 + b) * H + col, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] += v[e];
+                    }
+                }
+            }
+            if (col < H) {
+                float o[4];
+                load4<float>(dst + col, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += a[e];
+                store4<float>(dst + col, o);
+            }
+        }
+    }
+}
+
+// position-table gradient: gpos[s] (+)= sum_b de[b, s]  (fixed b order)
+__global__ __launch_bounds__(256) void embed_pos_grad_kernel(const float* __restrict__ de, float* __restrict__ gpos,
+                                                             int B, int S, int H, int accumulate) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)S * H) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += de[(long)b * S * H + idx];
+    gpos[idx] = accumulate ? gpos[idx] + s : s;
+}
+
+}  // namespace
+
+extern "C" size_t polus_layernorm_bwd_workspace_bytes(int rows, int H) {
+    return (size_t)ln_blocks(rows) * 3 * (size_t)H * sizeof(float);
+}
+
+extern "C" int polus_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta,
+                                   void* y, float* mean, float* rstd, int rows, int H, float eps, void* stream) {
+    POLUS_REQUIRE(x && gamma && beta && y && mean && rstd, "polus_layernorm_fwd: null pointer");
+    POLUS_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 256 * MAXC, "polus_layernorm_fwd: H=%d must be a multiple of 4, <= %d", H, 256 * MAXC);
+    POLUS_REQUIRE(polus_aligned16(x) && polus_aligned16(y) && polus_aligned16(gamma) && polus_aligned16(beta),
+                  "polus_layernorm_fwd: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks = (rows + WAVES - 1) / WAVES;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == POLUS_BF16)
+        POLUS_NC_DISPATCH(H, bf16_t, ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+    else if (dtype == POLUS_F32)
+        POLUS_NC_DISPATCH(H, float, ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, H, eps);
+    else POLUS_FAIL("polus_layernorm_fwd: bad dtype");
+    POLUS_CHECK_LAUNCH("polus_layernorm_fwd");
+    return POLUS_OK;
+}
+
+extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
+                                   const float* mean, const float* rstd, void* dx,
+                                   float* dgamma, float* dbeta, float* dbias, int accumulate,
+                                   int rows, int H, void* workspace, size_t workspace_bytes, void* stream) {
+    POLUS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "polus_layernorm_bwd: null pointer");
+    POLUS_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 256 * MAXC, "polus_layernorm_bwd: bad H=%d", H);
+    POLUS_REQUIRE(polus_aligned16(x) && polus_aligned16(dy) && polus_aligned16(dx) && polus_aligned16(gamma),
+                  "polus_layernorm_bwd: pointers must be 16-byte aligned");
+    size_t need = polus_layernorm_bwd_workspace_bytes(rows, H);
+    if (!workspace || workspace_bytes < need) { polus_set_error("polus_layernorm_bwd: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks = ln_blocks(rows);
+    float* partial = static_cast<float*>(workspace);
+    size_t lds = 3 * (size_t)H * sizeof(float);
+    int wb = dbias ? 1 : 0;
+    if (dtype == POLUS_BF16)
+        POLUS_NC_DISPATCH(H, bf16_t, ln_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb);
+    else if (dtype == POLUS_F32)
+        POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb);
+    else POLUS_FAIL("polus_layernorm_bwd: bad dtype");
+    POLUS_CHECK_LAUNCH("polus_layernorm_bwd");
+    int ncols = (wb ? 3 : 2) * H;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, st,
+                       partial, blocks, 3 * H, ncols, H, dgamma, dbeta, dbias, accumulate);
+    POLUS_CHECK_LAUNCH("polus_layernorm_bwd(finalize)");
+    return POLUS_OK;
+}
+
+extern "C" size_t polus_colsum_workspace_bytes(int rows, int cols) {
+    int chunks = (rows + 63) / 64;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    return (size_t)chunks * (size_t)cols * sizeof(float);
+}
+
+extern "C" int polus_colsum(int dtype, const void* x, long ldx, int rows, int cols, float* out, int accumulate,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    POLUS_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols, "polus_colsum: bad arguments");
+    POLUS_REQUIRE(dtype == POLUS_F32 || dtype == POLUS_BF16, "polus_colsum: bad dtype");
+    return colsum_launch(dtype, x, ldx, rows, cols, out, accumulate, nullptr, 0, workspace, workspace_bytes,
+                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t polus_embed_bwd_workspace_bytes(int B, int S, int H) {
+    size_t rows = (size_t)B * S;
+    size_t de = rows * H * sizeof(float);
+    size_t part = polus_layernorm_bwd_workspace_bytes((int)rows, H);
+    size_t cs = polus_colsum_workspace_bytes((int)rows, H);
+    return de + (part > cs ? part : cs) + 256;
+}
+
+extern "C" int polus_embed_ln_fwd(int dtype, const int32_t* ids, const int32_t* type_ids,
+                                  const float* word, const float* pos, const float* type,
+                                  const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                  int B, int S, int H, int vocab, int max_pos, int type_vocab, float eps,
+                                  void* stream) {
+    POLUS_REQUIRE(ids && word && pos && type && gamma && beta && y && mean && rstd, "polus_embed_ln_fwd: null pointer");
+    POLUS_REQUIRE(B > 0 && S > 0 && S <= max_pos, "polus_embed_ln_fwd: S=%d exceeds max_position_embeddings=%d", S, max_pos);
+    POLUS_REQUIRE(H % 4 == 0 && H <= 256 * MAXC && vocab > 0 && type_vocab > 0, "polus_embed_ln_fwd: bad H=%d", H);
+    POLUS_REQUIRE(polus_aligned16(word) && polus_aligned16(pos) && polus_aligned16(type) && polus_aligned16(y) &&
+                  polus_aligned16(gamma) && polus_aligned16(beta), "polus_embed_ln_fwd: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rows = B * S, blocks = (rows + WAVES - 1) / WAVES;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == POLUS_BF16)
+        POLUS_NC_DISPATCH(H, bf16_t, embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, ids, type_ids, word, pos, type, gamma, beta, (bf16_t*)y, mean, rstd, B, S, H, vocab, type_vocab, eps);
+    else if (dtype == POLUS_F32)
+        POLUS_NC_DISPATCH(H, float, embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, ids, type_ids, word, pos, type, gamma, beta, (float*)y, mean, rstd, B, S, H, vocab, type_vocab, eps);
+    else POLUS_FAIL("polus_embed_ln_fwd: bad dtype");
+    POLUS_CHECK_LAUNCH("polus_embed_ln_fwd");
+    return POLUS_OK;
+}
+
+extern "C" int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids, const int32_t* type_ids,
+                                  const float* word, const float* pos, const float* type, const float* gamma,
+                                  const float* mean, const float* rstd,
+                                  float* gword, float* gpos, float* gtype, float* ggamma, float* gbeta,
+                                  int accumulate, int deterministic,
+                                  int B, int S, int H, int vocab, int max_pos, int type_vocab,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    POLUS_REQUIRE(dy && ids && word && pos && type && gamma && mean && rstd && gword && gpos && gtype && ggamma && gbeta,
+                  "polus_embed_ln_bwd: null pointer");
+    POLUS_REQUIRE(B > 0 && S > 0 && S <= max_pos && H % 4 == 0 && H <= 256 * MAXC, "polus_embed_ln_bwd: bad shape");
+    POLUS_REQUIRE(polus_aligned16(dy) && polus_aligned16(gword) && polus_aligned16(workspace),
+                  "polus_embed_ln_bwd: pointers must be 16-byte aligned");
+    size_t need = polus_embed_bwd_workspace_bytes(B, S, H);
+    if (!workspace || workspace_bytes < need) { polus_set_error("polus_embed_ln_bwd: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = B * S;
+    float* de = static_cast<float*>(workspace);
+    size_t de_bytes = ((size_t)rows * H * sizeof(float) + 255) / 256 * 256;
+    float* partial = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + de_bytes);
+    size_t partial_bytes = workspace_bytes - de_bytes;
+    int blocks = ln_blocks(rows);
+    size_t lds = 3 * (size_t)H * sizeof(float);
+    if (dtype == POLUS_BF16)
+        POLUS_NC_DISPATCH(H, bf16_t, embed_bwd_ln_kernel, dim3(blocks), dim3(256), lds, st, (const bf16_t*)dy, ids, type_ids, word, pos, type, gamma, mean, rstd, de, partial, B, S, H, vocab, type_vocab);
+    else if (dtype == POLUS_F32)
+        POLUS_NC_DISPATCH(H, float, embed_bwd_ln_kernel, dim3(blocks), dim3(256), lds, st, (const float*)dy, ids, type_ids, word, pos, type, gamma, mean, rstd, de, partial, B, S, H, vocab, type_vocab);
+    else POLUS_FAIL("polus_embed_ln_bwd: bad dtype");
+    POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(ln)");
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * H + 63) / 64), dim3(1024), 0, st,
+                       partial, blocks, 3 * H, 2 * H, H, ggamma, gbeta, (float*)nullptr, accumulate);
+    POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(finalize)");
+
+    if (!accumulate) {
+        POLUS_HIP(hipMemsetAsync(gword, 0, (size_t)vocab * H * sizeof(float), st));
+        POLUS_HIP(hipMemsetAsync(gpos, 0, (size_t)max_pos * H * sizeof(float), st));
+    }
+    int sblocks = (rows + WAVES - 1) / WAVES;
+    if (sblocks > 4096) sblocks = 4096;
+    if (deterministic)
+        hipLaunchKernelGGL(embed_scatter_owner_kernel, dim3(sblocks), dim3(256), 0, st, de, ids, gword, rows, H, vocab);
+    else
+        hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(sblocks), dim3(256), 0, st, de, ids, gword, rows, H, vocab);
+    POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(scatter)");
+    hipLaunchKernelGGL(embed_pos_grad_kernel, dim3(((long)S * H + 255) / 256), dim3(256), 0, st, de, gpos, B, S, H, accumulate);
+    POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(pos)");
+    for (int t = 0; t < type_vocab; ++t) {
+        if (type_ids) {
+            int rc = colsum_launch(POLUS_F32, de, H, rows, H, gtype + (long)t * H, accumulate, type_ids, t, partial, partial_bytes, st);
+            if (rc != POLUS_OK) return rc;
+        } else if (t == 0) {
+            int rc = colsum_launch(POLUS_F32, de, H, rows, H, gtype, accumulate, nullptr, 0, partial, partial_bytes, st);
+            if (rc != POLUS_OK) return rc;
+        } else if (!accumulate) {
+            POLUS_HIP(hipMemsetAsync(gtype + (long)t * H, 0, (size_t)H * sizeof(float), st));
+        }
+    }
+    return POLUS_OK;
+}

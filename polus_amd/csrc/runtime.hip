@@ -1,0 +1,99 @@
+// Error plumbing, device query and the small elementwise utilities of the C ABI.
+#include "common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void polus_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* polus_last_error(void) { return g_err; }
+extern "C" int polus_abi_version(void) { return POLUS_ABI_VERSION; }
+
+extern "C" int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len) {
+    int dev = 0;
+    POLUS_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    POLUS_HIP(hipGetDeviceProperties(&prop, dev));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    return POLUS_OK;
+}
+
+namespace {
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i4 < n; i4 += stride) {
+        if (i4 + 4 <= n) {
+            float v[4];
+            load4<S>(src + i4, v);
+            store4<D>(dst + i4, v);
+        } else {
+            for (int64_t j = i4; j < n; ++j) dst[j] = from_f<D>(to_f<S>(src[j]));
+        }
+    }
+}
+
+__global__ void scale_kernel(float* __restrict__ x, float a, int64_t n) {
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i4 < n; i4 += stride) {
+        if (i4 + 4 <= n) {
+            float4 v = *reinterpret_cast<float4*>(x + i4);
+            v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+            *reinterpret_cast<float4*>(x + i4) = v;
+        } else {
+            for (int64_t j = i4; j < n; ++j) x[j] *= a;
+        }
+    }
+}
+
+inline int stream_grid(int64_t n) {
+    int64_t b = (n / 4 + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;  // memory-bound: cap and grid-stride
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int polus_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream) {
+    POLUS_REQUIRE(src && dst && n >= 0, "polus_cast: bad arguments");
+    if (n == 0) return POLUS_OK;
+    POLUS_REQUIRE(((uintptr_t)src % (4 * polus_dtype_size(src_dtype))) == 0 &&
+                  ((uintptr_t)dst % (4 * polus_dtype_size(dst_dtype))) == 0,
+                  "polus_cast: pointers must be 4-element aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(stream_grid(n)), block(256);
+    if (src_dtype == POLUS_F32 && dst_dtype == POLUS_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == POLUS_BF16 && dst_dtype == POLUS_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == POLUS_F32 && dst_dtype == POLUS_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, st, (const float*)src, (float*)dst, n);
+    else if (src_dtype == POLUS_BF16 && dst_dtype == POLUS_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else POLUS_FAIL("polus_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+    POLUS_CHECK_LAUNCH("polus_cast");
+    return POLUS_OK;
+}
+
+extern "C" int polus_scale(float* x, float a, int64_t n, void* stream) {
+    POLUS_REQUIRE(x && n >= 0, "polus_scale: bad arguments");
+    if (n == 0) return POLUS_OK;
+    POLUS_REQUIRE(((uintptr_t)x % 16) == 0, "polus_scale: pointer must be 16-byte aligned");
+    hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, a, n);
+    POLUS_CHECK_LAUNCH("polus_scale");
+    return POLUS_OK;
+}

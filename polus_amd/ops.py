@@ -1,0 +1,256 @@
+"""Host-side launchers: torch tensors in, raw pointers through the C ABI, nothing computed here.
+
+torch is the allocator and the stream owner only.  Every function launches on torch's
+current stream and returns without synchronising.
+"""
+import torch
+
+from . import _lib
+from ._lib import (F32, BF16, K_CONTIG, K_STRIDED, ACT_NONE, ACT_GELU, ACT_SWISH, ACT_RELU, ACT_TANH,
+                   GEMM_ACCUM_C, GEMM_ACT_FWD, GEMM_ACT_BWD, check, ptr, dtype_code)
+
+ACT_CODES = {None: ACT_NONE, "linear": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
+             "relu": ACT_RELU, "tanh": ACT_TANH}
+
+
+class Workspace:
+    """Grow-only device scratch. Kernels on one stream run in order, so one buffer per
+    stream is enough; it is sized during the first step and never reallocated after."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if self.buf is None or self.buf.numel() < nbytes:
+            # drop the old buffer only after queued kernels are done with it
+            if self.buf is not None:
+                torch.cuda.current_stream().synchronize()
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+_WS = {}
+
+
+def workspace(device):
+    key = (str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = Workspace(device)
+    return ws
+
+
+def _st():
+    return _lib.current_stream()
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PolusHipError("polus_amd ops need device (HBM) tensors; there is no CPU path")
+
+
+def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=None, alpha=1.0,
+         bias=None, resid=None, aux=None, act=None, flags=0, split_k=1):
+    """out[M,N] = epilogue(alpha * A_op . B_op); see include/polus_hip.h polus_gemm."""
+    lib = _lib.load()
+    _req_cuda(a, b, out, bias, resid, aux)
+    dt = dtype_code(a.dtype)
+    assert b.dtype == a.dtype and a.dim() == 2 and b.dim() == 2 and out.dim() == 2
+    if a_layout == K_CONTIG:
+        m_, k_ = a.shape
+    else:
+        k_, m_ = a.shape
+    if b_layout == K_CONTIG:
+        n_, kb_ = b.shape
+    else:
+        kb_, n_ = b.shape
+    M = m_ if M is None else M
+    N = n_ if N is None else N
+    K = k_ if K is None else K
+    assert kb_ == k_, f"contraction mismatch {k_} vs {kb_}"
+    assert out.shape[0] >= M and out.shape[1] >= N
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    ws = None
+    ws_bytes = 0
+    if split_k > 1:
+        ws_bytes = lib.polus_gemm_workspace_bytes(M, N, split_k)
+        ws = workspace(a.device).get(ws_bytes)
+    check(lib.polus_gemm(dt, a_layout, b_layout, dtype_code(out.dtype),
+                         ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+                         M, N, K, float(alpha), ptr(bias),
+                         ptr(resid), resid.stride(0) if resid is not None else 0,
+                         ptr(aux), aux.stride(0) if aux is not None else 0,
+                         ACT_CODES[act] if not isinstance(act, int) else act, flags, split_k,
+                         ptr(ws), ws_bytes, _st()), "polus_gemm")
+    return out
+
+
+def attention_fwd(qkv, mask, ctx, lse, B, S, n_heads):
+    lib = _lib.load()
+    _req_cuda(qkv, mask, ctx, lse)
+    H = n_heads * 64
+    assert qkv.shape == (B * S, 3 * H) and ctx.shape == (B * S, H) and qkv.is_contiguous() and ctx.is_contiguous()
+    assert lse.dtype == torch.float32 and lse.numel() == B * n_heads * S
+    assert mask is None or (mask.dtype == torch.int32 and mask.numel() == B * S and mask.is_contiguous())
+    check(lib.polus_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), ptr(mask), ptr(ctx), ptr(lse),
+                                  B, S, n_heads, 64, _st()), "polus_attention_fwd")
+
+
+def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, n_heads):
+    lib = _lib.load()
+    _req_cuda(qkv, mask, ctx, dctx, lse, dqkv)
+    H = n_heads * 64
+    assert qkv.shape == (B * S, 3 * H) and dqkv.shape == (B * S, 3 * H) and dctx.shape == (B * S, H)
+    assert qkv.is_contiguous() and dqkv.is_contiguous() and dctx.is_contiguous() and ctx.is_contiguous()
+    nb = lib.polus_attention_bwd_workspace_bytes(B, S, n_heads)
+    ws = workspace(qkv.device).get(nb)
+    check(lib.polus_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), ptr(mask), ptr(ctx), ptr(dctx), ptr(lse),
+                                  ptr(dqkv), B, S, n_heads, 64, ptr(ws), nb, _st()), "polus_attention_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
+    lib = _lib.load()
+    _req_cuda(x, gamma, beta, y, mean, rstd)
+    rows, H = x.shape
+    assert x.is_contiguous() and y.is_contiguous() and y.shape == x.shape
+    check(lib.polus_layernorm_fwd(dtype_code(x.dtype), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+                                  rows, H, float(eps), _st()), "polus_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias=None, accumulate=False):
+    lib = _lib.load()
+    _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias)
+    rows, H = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous()
+    nb = lib.polus_layernorm_bwd_workspace_bytes(rows, H)
+    ws = workspace(x.device).get(nb)
+    check(lib.polus_layernorm_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                  ptr(dgamma), ptr(dbeta), ptr(dbias), int(accumulate), rows, H,
+                                  ptr(ws), nb, _st()), "polus_layernorm_bwd")
+
+
+def embed_ln_fwd(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd, eps):
+    lib = _lib.load()
+    _req_cuda(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd)
+    B, S = ids.shape
+    V, H = word.shape
+    assert ids.dtype == torch.int32 and ids.is_contiguous()
+    assert type_ids is None or (type_ids.dtype == torch.int32 and type_ids.is_contiguous())
+    check(lib.polus_embed_ln_fwd(dtype_code(y.dtype), ptr(ids), ptr(type_ids), ptr(word), ptr(pos), ptr(typ),
+                                 ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+                                 B, S, H, V, pos.shape[0], typ.shape[0], float(eps), _st()), "polus_embed_ln_fwd")
+
+
+def embed_ln_bwd(dy, ids, type_ids, word, pos, typ, gamma, mean, rstd, gword, gpos, gtyp, ggamma, gbeta,
+                 accumulate=False, deterministic=False):
+    lib = _lib.load()
+    _req_cuda(dy, ids, word, gword)
+    B, S = ids.shape
+    V, H = word.shape
+    nb = lib.polus_embed_bwd_workspace_bytes(B, S, H)
+    ws = workspace(dy.device).get(nb)
+    check(lib.polus_embed_ln_bwd(dtype_code(dy.dtype), ptr(dy), ptr(ids), ptr(type_ids), ptr(word), ptr(pos), ptr(typ),
+                                 ptr(gamma), ptr(mean), ptr(rstd), ptr(gword), ptr(gpos), ptr(gtyp), ptr(ggamma),
+                                 ptr(gbeta), int(accumulate), int(deterministic),
+                                 B, S, H, V, pos.shape[0], typ.shape[0], ptr(ws), nb, _st()), "polus_embed_ln_bwd")
+
+
+def colsum(x, out, accumulate=False, rows=None, cols=None):
+    lib = _lib.load()
+    _req_cuda(x, out)
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    nb = lib.polus_colsum_workspace_bytes(rows, cols)
+    ws = workspace(x.device).get(nb)
+    check(lib.polus_colsum(dtype_code(x.dtype), ptr(x), x.stride(0), rows, cols, ptr(out), int(accumulate),
+                           ptr(ws), nb, _st()), "polus_colsum")
+
+
+def softmax_xent(logits, labels, loss, dlogits, class_weights=None, rows=None, C=None):
+    lib = _lib.load()
+    _req_cuda(logits, labels, loss, dlogits, class_weights)
+    rows = logits.shape[0] if rows is None else rows
+    C = logits.shape[1] if C is None else C
+    assert logits.dtype == torch.float32 and labels.dtype == torch.int32 and loss.dtype == torch.float32
+    nb = lib.polus_loss_workspace_bytes(rows)
+    ws = workspace(logits.device).get(nb)
+    check(lib.polus_softmax_xent(dtype_code(dlogits.dtype), ptr(logits), logits.stride(0), ptr(labels),
+                                 ptr(class_weights), ptr(loss), ptr(dlogits), dlogits.stride(0), rows, C,
+                                 ptr(ws), nb, _st()), "polus_softmax_xent")
+
+
+def sigmoid_xent(logits, y_true, class_weights, negative_weight, loss, dlogits):
+    lib = _lib.load()
+    _req_cuda(logits, y_true, class_weights, loss, dlogits)
+    rows, C = logits.shape
+    nb = lib.polus_loss_workspace_bytes(rows)
+    ws = workspace(logits.device).get(nb)
+    check(lib.polus_sigmoid_xent(dtype_code(dlogits.dtype), ptr(logits), logits.stride(0), ptr(y_true), y_true.stride(0),
+                                 ptr(class_weights), float(negative_weight), ptr(loss), ptr(dlogits), dlogits.stride(0),
+                                 rows, C, ptr(ws), nb, _st()), "polus_sigmoid_xent")
+
+
+def crf_nll(potentials, tags, lengths, trans, sample_w, loss, dpot, dtrans, accumulate=False):
+    lib = _lib.load()
+    _req_cuda(potentials, tags, lengths, trans, sample_w, loss, dpot, dtrans)
+    B, S, C = potentials.shape
+    assert potentials.dtype == torch.float32 and potentials.is_contiguous() and dpot.is_contiguous()
+    nb = lib.polus_crf_workspace_bytes(B, S, C)
+    ws = workspace(potentials.device).get(nb)
+    check(lib.polus_crf_nll(dtype_code(dpot.dtype), ptr(potentials), ptr(tags), ptr(lengths), ptr(trans), ptr(sample_w),
+                            ptr(loss), ptr(dpot), ptr(dtrans), int(accumulate), B, S, C, ptr(ws), nb, _st()),
+          "polus_crf_nll")
+
+
+def crf_viterbi(potentials, lengths, trans, out_tags):
+    lib = _lib.load()
+    _req_cuda(potentials, lengths, trans, out_tags)
+    B, S, C = potentials.shape
+    nb = lib.polus_crf_workspace_bytes(B, S, C)
+    ws = workspace(potentials.device).get(nb)
+    check(lib.polus_crf_viterbi(ptr(potentials), ptr(lengths), ptr(trans), ptr(out_tags), B, S, C, ptr(ws), nb, _st()),
+          "polus_crf_viterbi")
+
+
+def argmax(x, out, rows=None, C=None):
+    lib = _lib.load()
+    _req_cuda(x, out)
+    rows = x.shape[0] if rows is None else rows
+    C = x.shape[1] if C is None else C
+    check(lib.polus_argmax(ptr(x), x.stride(0), ptr(out), rows, C, _st()), "polus_argmax")
+
+
+def adam_step(p, g, m, v, shadow, seg, n_seg, lr, lr_t, beta1, beta2, eps, weight_decay, grad_scale=1.0,
+              clip_scale=None):
+    lib = _lib.load()
+    _req_cuda(p, g, m, v, shadow, seg, clip_scale)
+    check(lib.polus_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), ptr(seg), n_seg, p.numel(),
+                              float(lr), float(lr_t), float(beta1), float(beta2), float(eps), float(weight_decay),
+                              float(grad_scale), ptr(clip_scale), _st()), "polus_adam_step")
+
+
+def sqnorm(g, out):
+    lib = _lib.load()
+    _req_cuda(g, out)
+    nb = lib.polus_sqnorm_workspace_bytes(g.numel())
+    ws = workspace(g.device).get(nb)
+    check(lib.polus_sqnorm(ptr(g), g.numel(), ptr(out), ptr(ws), nb, _st()), "polus_sqnorm")
+
+
+def clip_scale(sq, grad_scale, clip_norm, out):
+    check(_lib.load().polus_clip_scale(ptr(sq), float(grad_scale), float(clip_norm), ptr(out), _st()), "polus_clip_scale")
+
+
+def cast(src, dst):
+    _req_cuda(src, dst)
+    assert src.numel() == dst.numel()
+    check(_lib.load().polus_cast(dtype_code(src.dtype), ptr(src), dtype_code(dst.dtype), ptr(dst), src.numel(), _st()),
+          "polus_cast")
+
+
+def scale_(x, a):
+    _req_cuda(x)
+    check(_lib.load().polus_scale(ptr(x), float(a), x.numel(), _st()), "polus_scale")

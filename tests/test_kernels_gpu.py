@@ -1,0 +1,405 @@
+"""Per-kernel parity: HIP kernels (through the C ABI) vs the CPU oracle on seeded inputs.
+
+Tolerances: f32 path 2e-5 of max|ref| (exact-f32 MFMA, different summation order only);
+bf16 path 1.5e-2 of max|ref| against the oracle evaluated on the bf16-rounded inputs
+(bf16 storage of outputs, f32 accumulation)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert as ob
+from oracle import losses as ol
+from oracle import optim as oo
+from tests.util import TOL, assert_close, dev, host, rounded
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from polus_amd import ops as _ops
+    return _ops
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+# ------------------------------------------------------------------------------- GEMM
+def _layout(a, layout):
+    return a if layout == 0 else np.ascontiguousarray(a.T)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("al,bl", [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 192), (128, 128, 64), (100, 72, 136), (97, 50, 75), (5, 4, 768)])
+def test_gemm_layouts(ops, dtype, al, bl, M, N, K):
+    r = rng(M * 7 + N * 3 + K + al * 2 + bl)
+    A = r.standard_normal((M, K))
+    B = r.standard_normal((N, K))
+    a_t, b_t = dev(_layout(A, al), dtype), dev(_layout(B, bl), dtype)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+    ops.gemm(a_t, b_t, out, a_layout=al, b_layout=bl)
+    ref = rounded(A, dtype) @ rounded(B, dtype).T
+    assert_close(host(out), ref, TOL[dtype], f"gemm {al}{bl} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(ops, dtype):
+    # A = I with an asymmetric B catches a transposed C write or a swapped fragment map
+    n = 128
+    A = np.eye(n)
+    B = (np.arange(n)[:, None] * 3 + np.arange(n)[None, :] % 7).astype(np.float64) / 64.0
+    out = torch.zeros((n, n), dtype=dtype, device="cuda")
+    ops.gemm(dev(A, dtype), dev(B, dtype), out)          # out = A @ B^T = B^T
+    assert_close(host(out), rounded(B, dtype).T, 1e-6 if dtype == torch.float32 else 4e-3, "identity")
+    for al, bl in [(0, 1), (1, 1), (1, 0)]:
+        out.zero_()
+        ops.gemm(dev(_layout(A, al), dtype), dev(_layout(B, bl), dtype), out, a_layout=al, b_layout=bl)
+        assert_close(host(out), rounded(B, dtype).T, 1e-6 if dtype == torch.float32 else 4e-3, f"identity {al}{bl}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 200, 136, 96
+    r = rng(5)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.2
+    bias = r.standard_normal(N)
+    R = r.standard_normal((M, N))
+    a_t, b_t = dev(A, dtype), dev(B, dtype)
+    bias_t, r_t = dev(bias, torch.float32), dev(R, dtype)
+    base = rounded(A, dtype) @ rounded(B, dtype).T
+    tol = TOL[dtype]
+    # bias + residual
+    out = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm(a_t, b_t, out, bias=bias_t, resid=r_t)
+    assert_close(host(out), base + bias + rounded(R, dtype), tol, "bias+resid")
+    # bias + gelu forward with pre-activation saved
+    aux = torch.empty((M, N), dtype=dtype, device="cuda")
+    ops.gemm(a_t, b_t, out, bias=bias_t, aux=aux, act="gelu", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(aux), base + bias, tol, "gelu aux")
+    assert_close(host(out), ob.gelu(base + bias), tol, "gelu out")
+    # activation backward: C = (A.B) * gelu'(aux)
+    u = host(aux)
+    ops.gemm(a_t, b_t, out, aux=aux, act="gelu", flags=ops.GEMM_ACT_BWD)
+    assert_close(host(out), base * ob.gelu_grad(u), tol, "gelu bwd")
+    ops.gemm(a_t, b_t, out, bias=bias_t, aux=aux, act="swish", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(out), ob.swish(base + bias), tol, "swish out")
+    # alpha + accumulate into an f32 C (gradient accumulation), also with split-K
+    c32 = dev(R, torch.float32)
+    ops.gemm(a_t, b_t, c32, alpha=0.5, flags=ops.GEMM_ACCUM_C)
+    assert_close(host(c32), 0.5 * base + R.astype(np.float32), tol, "accum f32")
+    c32 = dev(R, torch.float32)
+    ops.gemm(a_t, b_t, c32, alpha=0.5, flags=ops.GEMM_ACCUM_C, split_k=3, bias=bias_t)
+    assert_close(host(c32), 0.5 * base + bias + R.astype(np.float32), tol, "accum f32 split-k")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dw_shape_splitk(ops, dtype):
+    # dW = dY^T X with a long contraction, both operands K-strided, f32 output, split-K
+    T, N, K = 2048, 192, 160
+    r = rng(11)
+    dY, X = r.standard_normal((T, N)) * 0.1, r.standard_normal((T, K))
+    out = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    ref = rounded(dY, dtype).T @ rounded(X, dtype)
+    for sk in (1, 4, 7):
+        out.fill_(float("nan"))
+        ops.gemm(dev(dY, dtype), dev(X, dtype), out, a_layout=1, b_layout=1, split_k=sk)
+        assert_close(host(out), ref, 3e-5 if dtype == torch.float32 else 2e-3, f"dW split_k={sk}")
+    # bitwise reproducible
+    o1 = out.clone()
+    ops.gemm(dev(dY, dtype), dev(X, dtype), out, a_layout=1, b_layout=1, split_k=7)
+    assert torch.equal(o1, out)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_bert_shapes(ops, dtype):
+    T, H, I = 512, 768, 3072
+    r = rng(3)
+    X, W = r.standard_normal((T, H)), r.standard_normal((I, H)) * 0.02
+    out = torch.empty((T, I), dtype=dtype, device="cuda")
+    ops.gemm(dev(X, dtype), dev(W, dtype), out)
+    assert_close(host(out), rounded(X, dtype) @ rounded(W, dtype).T, TOL[dtype], "ffn1")
+    dY = r.standard_normal((T, I)) * 0.1
+    dx = torch.empty((T, H), dtype=dtype, device="cuda")
+    ops.gemm(dev(dY, dtype), dev(W, dtype), dx, b_layout=1)
+    assert_close(host(dx), rounded(dY, dtype) @ rounded(W, dtype), TOL[dtype], "dX")
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from polus_amd._lib import PolusHipError
+    a = torch.zeros((8, 8), device="cuda")
+    with pytest.raises(PolusHipError):
+        ops.gemm(a, a, torch.zeros((8, 8), device="cuda"), aux=None, act="gelu", flags=ops.GEMM_ACT_BWD)
+    with pytest.raises(PolusHipError):
+        ops.gemm(a.cpu(), a.cpu(), a.cpu())
+
+
+# ------------------------------------------------------------------------------- attention
+def _attn_case(B, S, A, seed, full_mask=False):
+    r = rng(seed)
+    H = A * 64
+    qkv = r.standard_normal((B, S, 3 * H)) * 0.7
+    lens = r.integers(max(1, S // 2), S + 1, size=B)
+    mask = (np.arange(S)[None] < lens[:, None]).astype(np.int32)
+    if full_mask:
+        mask[:] = 1
+    dctx = r.standard_normal((B, S, H))
+    return qkv, mask, dctx
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,A", [(2, 64, 2), (3, 48, 2), (1, 200, 3), (2, 256, 12), (1, 512, 2), (2, 17, 1)])
+def test_attention_fwd_bwd(ops, dtype, B, S, A):
+    qkv, mask, dctx = _attn_case(B, S, A, seed=B * 100 + S + A)
+    H = A * 64
+    q_r = rounded(qkv, dtype)
+    ctx_ref, probs = ob.attention_fwd(q_r, ob.additive_mask(mask, np.float64), A)
+    qkv_t = dev(qkv.reshape(B * S, 3 * H), dtype)
+    mask_t = dev(mask)
+    ctx = torch.full((B * S, H), float("nan"), dtype=dtype, device="cuda")
+    lse = torch.empty((B, A, S), dtype=torch.float32, device="cuda")
+    ops.attention_fwd(qkv_t, mask_t, ctx, lse, B, S, A)
+    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert_close(host(ctx).reshape(B, S, H), ctx_ref, tol, "ctx")
+    # log-sum-exp of the masked scaled scores
+    q = q_r[..., :H].reshape(B, S, A, 64).transpose(0, 2, 1, 3)
+    k = q_r[..., H:2 * H].reshape(B, S, A, 64).transpose(0, 2, 1, 3)
+    sc = q @ k.transpose(0, 1, 3, 2) / 8.0 + ob.additive_mask(mask, np.float64)
+    mx = sc.max(-1, keepdims=True)
+    lse_ref = (mx + np.log(np.exp(sc - mx).sum(-1, keepdims=True)))[..., 0]
+    assert np.abs(host(lse) - lse_ref).max() < (1e-3 if dtype == torch.float32 else 5e-2)
+    # backward
+    dqkv_ref = ob.attention_bwd(rounded(dctx, dtype), q_r, probs, A)
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=dtype, device="cuda")
+    ops.attention_bwd(qkv_t, mask_t, ctx, dev(dctx.reshape(B * S, H), dtype), lse, dqkv, B, S, A)
+    out = host(dqkv).reshape(B, S, 3 * H)
+    for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert_close(out[..., sl], dqkv_ref[..., sl], 1e-4 if dtype == torch.float32 else 3e-2, nm)
+
+
+def test_attention_no_mask_and_all_masked_row(ops):
+    B, S, A = 2, 64, 1
+    qkv, mask, _ = _attn_case(B, S, A, 9, full_mask=True)
+    ctx_ref, _ = ob.attention_fwd(qkv, ob.additive_mask(mask, np.float64), A)
+    ctx = torch.empty((B * S, 64), device="cuda")
+    lse = torch.empty((B, A, S), device="cuda")
+    ops.attention_fwd(dev(qkv.reshape(B * S, 192), torch.float32), None, ctx, lse, B, S, A)
+    assert_close(host(ctx).reshape(B, S, 64), ctx_ref, 5e-5, "no mask")
+    # a sample whose mask is all zeros: -10000 on every key is shift-invariant (reference semantics)
+    mask[1] = 0
+    ctx_ref, _ = ob.attention_fwd(qkv, ob.additive_mask(mask, np.float64), A)
+    ops.attention_fwd(dev(qkv.reshape(B * S, 192), torch.float32), dev(mask), ctx, lse, B, S, A)
+    assert_close(host(ctx).reshape(B, S, 64), ctx_ref, 5e-5, "all-masked sample")
+
+
+# ------------------------------------------------------------------------------- LayerNorm / embeddings
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,H", [(37, 128), (1000, 768), (64, 1024), (5, 2048), (3, 64)])
+def test_layernorm(ops, dtype, rows, H):
+    r = rng(rows + H)
+    x = r.standard_normal((rows, H)) * 2 + 0.5
+    g, b = 1 + 0.1 * r.standard_normal(H), 0.1 * r.standard_normal(H)
+    dy = r.standard_normal((rows, H))
+    xr, dyr = rounded(x, dtype), rounded(dy, dtype)
+    y_ref, mean_ref, rstd_ref = ob.layer_norm_fwd(xr, g.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64), 1e-12)
+    x_t, g_t, b_t = dev(x, dtype), dev(g, torch.float32), dev(b, torch.float32)
+    y = torch.empty_like(x_t)
+    mean = torch.empty(rows, device="cuda")
+    rstd = torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x_t, g_t, b_t, y, mean, rstd, 1e-12)
+    tol = TOL[dtype]
+    assert_close(host(y), y_ref, tol, "ln y")
+    assert_close(host(mean), mean_ref, 1e-5, "mean")
+    assert_close(host(rstd), rstd_ref, 1e-5, "rstd")
+    dx_ref, dg_ref, db_ref = ob.layer_norm_bwd(dyr, xr, host(g_t), mean_ref, rstd_ref)
+    dx = torch.empty_like(x_t)
+    dg = torch.full((H,), float("nan"), device="cuda")
+    db = torch.full((H,), float("nan"), device="cuda")
+    dbias = torch.full((H,), float("nan"), device="cuda")
+    ops.layernorm_bwd(dev(dy, dtype), x_t, g_t, mean, rstd, dx, dg, db, dbias)
+    assert_close(host(dx), dx_ref, tol, "ln dx")
+    assert_close(host(dg), dg_ref, 1e-4, "dgamma")
+    assert_close(host(db), db_ref, 1e-4, "dbeta")
+    assert_close(host(dbias), host(dx).sum(0), 1e-4 if dtype == torch.float32 else 2e-2, "dbias")
+    # accumulate
+    ops.layernorm_bwd(dev(dy, dtype), x_t, g_t, mean, rstd, dx, dg, db, None, accumulate=True)
+    assert_close(host(dg), 2 * dg_ref, 1e-4, "dgamma accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_embeddings(ops, dtype, deterministic):
+    cfg = ob.BertConfig(vocab_size=300, hidden_size=128, max_position_embeddings=64)
+    B, S = 5, 40
+    r = rng(21)
+    p = {k: v.astype(np.float64) for k, v in ob.init_params(cfg, with_embeddings=True).items() if k.startswith("emb")}
+    p["emb.ln.g"] = p["emb.ln.g"] + 0.1 * r.standard_normal(128)
+    p["emb.ln.b"] = 0.1 * r.standard_normal(128)
+    p = {k: v.astype(np.float32).astype(np.float64) for k, v in p.items()}
+    ids = r.integers(0, 300, size=(B, S)).astype(np.int32)
+    ids[:, 30:] = 0  # heavy duplicates (padding id)
+    tt = r.integers(0, 2, size=(B, S)).astype(np.int32)
+    y_ref, cache = ob.embeddings_fwd(p, cfg, ids, tt)
+    t = {k: dev(v, torch.float32) for k, v in p.items()}
+    y = torch.empty((B * S, 128), dtype=dtype, device="cuda")
+    mean = torch.empty(B * S, device="cuda")
+    rstd = torch.empty(B * S, device="cuda")
+    ops.embed_ln_fwd(dev(ids), dev(tt), t["emb.word"], t["emb.pos"], t["emb.type"], t["emb.ln.g"], t["emb.ln.b"],
+                     y, mean, rstd, 1e-12)
+    assert_close(host(y).reshape(B, S, 128), y_ref, TOL[dtype], "embed y")
+    dy = r.standard_normal((B, S, 128))
+    g_ref = ob.embeddings_bwd(rounded(dy, dtype), p, cfg, cache)
+    gw = torch.full_like(t["emb.word"], float("nan"))
+    gp = torch.full_like(t["emb.pos"], float("nan"))
+    gt = torch.full_like(t["emb.type"], float("nan"))
+    gg = torch.full((128,), float("nan"), device="cuda")
+    gb = torch.full((128,), float("nan"), device="cuda")
+    args = (dev(dy.reshape(B * S, 128), dtype), dev(ids), dev(tt), t["emb.word"], t["emb.pos"], t["emb.type"],
+            t["emb.ln.g"], mean, rstd, gw, gp, gt, gg, gb)
+    ops.embed_ln_bwd(*args, deterministic=deterministic)
+    for nm, got in (("emb.word", gw), ("emb.pos", gp), ("emb.type", gt), ("emb.ln.g", gg), ("emb.ln.b", gb)):
+        assert_close(host(got), g_ref[nm], 1e-4, nm)
+    if deterministic:
+        first = gw.clone()
+        ops.embed_ln_bwd(*args, deterministic=True)
+        assert torch.equal(first, gw)
+    ops.embed_ln_bwd(*args, accumulate=True, deterministic=deterministic)
+    assert_close(host(gw), 2 * g_ref["emb.word"], 1e-4, "word accumulate")
+    assert_close(host(gt), 2 * g_ref["emb.type"], 1e-4, "type accumulate")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(1000, 768), (33, 10), (4096, 2304)])
+def test_colsum(ops, dtype, rows, cols):
+    x = rng(rows).standard_normal((rows, cols))
+    out = torch.full((cols,), float("nan"), device="cuda")
+    ops.colsum(dev(x, dtype), out)
+    assert_close(host(out), rounded(x, dtype).sum(0), 1e-4, "colsum")
+    ops.colsum(dev(x, dtype), out, accumulate=True)
+    assert_close(host(out), 2 * rounded(x, dtype).sum(0), 1e-4, "colsum accumulate")
+
+
+# ------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(64, 4), (1000, 10), (3, 3)])
+def test_softmax_xent(ops, dtype, rows, C):
+    r = rng(rows + C)
+    logits = (r.standard_normal((rows, C)) * 3).astype(np.float32)
+    labels = r.integers(0, C, size=rows).astype(np.int32)
+    loss_ref, d_ref = ol.sparse_softmax_xent_fwd(logits.astype(np.float64), labels)
+    loss = torch.empty(1, device="cuda")
+    d = torch.empty((rows, C), dtype=dtype, device="cuda")
+    ops.softmax_xent(dev(logits), dev(labels), loss, d)
+    assert abs(float(loss) - loss_ref) < 1e-5 * max(1, abs(loss_ref))
+    assert_close(host(d), d_ref, 1e-5 if dtype == torch.float32 else 1e-2, "dlogits")
+    cw = r.uniform(0.5, 2.0, size=C)
+    onehot = np.eye(C)[labels]
+    loss_ref, d_ref = ol.weighted_softmax_xent_fwd(cw, onehot, logits.astype(np.float64))
+    ops.softmax_xent(dev(logits), dev(labels), loss, d, class_weights=dev(cw, torch.float32))
+    assert abs(float(loss) - loss_ref) < 1e-5 * max(1, abs(loss_ref))
+    assert_close(host(d), d_ref, 1e-5 if dtype == torch.float32 else 1e-2, "weighted dlogits")
+
+
+def test_sigmoid_xent(ops):
+    rows, C = 200, 5
+    r = rng(8)
+    logits = (r.standard_normal((rows, C)) * 2).astype(np.float32)
+    y = (r.uniform(size=(rows, C)) < 0.3).astype(np.float32)
+    y[:20] = 0
+    cw = r.uniform(0.5, 2.0, size=C)
+    loss_ref, d_ref = ol.weighted_sigmoid_xent_fwd(cw, 0.3, y.astype(np.float64), logits.astype(np.float64))
+    loss = torch.empty(1, device="cuda")
+    d = torch.empty((rows, C), device="cuda")
+    ops.sigmoid_xent(dev(logits), dev(y), dev(cw, torch.float32), 0.3, loss, d)
+    assert abs(float(loss) - loss_ref) < 1e-5 * max(1, abs(loss_ref))
+    assert_close(host(d), d_ref, 1e-5, "sigmoid dlogits")
+
+
+@pytest.mark.parametrize("B,S,C", [(4, 12, 3), (7, 50, 4), (2, 1, 5)])
+def test_crf(ops, B, S, C):
+    r = rng(B + S + C)
+    pot = r.standard_normal((B, S, C)).astype(np.float32)
+    tags = r.integers(0, C, size=(B, S)).astype(np.int32)
+    lengths = r.integers(1, S + 1, size=B).astype(np.int32)
+    lengths[0] = S
+    trans = (r.standard_normal((C, C)) * 0.5).astype(np.float32)
+    onehot = np.eye(C)[tags]
+    sw = r.uniform(0.5, 1.5, size=B).astype(np.float32)
+    for weights in (None, sw):
+        loss_ref, dx_ref, dT_ref = ol.crf_nll_fwd(onehot, pot, lengths, trans, None, weights)
+        loss = torch.empty(1, device="cuda")
+        dpot = torch.full((B, S, C), float("nan"), device="cuda")
+        dT = torch.full((C, C), float("nan"), device="cuda")
+        ops.crf_nll(dev(pot), dev(tags), dev(lengths), dev(trans), None if weights is None else dev(weights), loss, dpot, dT)
+        assert abs(float(loss) - loss_ref) < 2e-5 * max(1, abs(loss_ref))
+        assert_close(host(dpot), dx_ref, 2e-5, "crf dpot")
+        assert_close(host(dT), dT_ref, 5e-5, "crf dtrans")
+    dec_ref = ol.crf_viterbi(pot, lengths, trans)
+    dec = torch.empty((B, S), dtype=torch.int32, device="cuda")
+    ops.crf_viterbi(dev(pot), dev(lengths), dev(trans), dec)
+    assert np.array_equal(dec.cpu().numpy(), dec_ref)
+
+
+def test_argmax(ops):
+    x = rng(4).standard_normal((300, 7)).astype(np.float32)
+    x[5, 2] = x[5, 4] = 9.0  # tie -> first index
+    out = torch.empty(300, dtype=torch.int32, device="cuda")
+    ops.argmax(dev(x), out)
+    assert np.array_equal(out.cpu().numpy(), x.argmax(-1))
+
+
+# ------------------------------------------------------------------------------- optimizer
+def test_adam_matches_oracle(ops):
+    r = rng(13)
+    sizes = [("a.w", 1000), ("a.b", 37), ("ln.g", 64), ("c.w", 4099)]
+    params = {k: r.standard_normal(n).astype(np.float32) for k, n in sizes}
+    opt = oo.Adam(lr=lambda t: oo.warmup_linear_lr(t, 10, 1e-2), weight_decay=0.01,
+                  no_decay=[k for k, _ in sizes if oo.is_no_decay(k)])
+    n = sum(s for _, s in sizes)
+    flat = np.concatenate([params[k] for k, _ in sizes])
+    p = dev(flat)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    shadow = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    seg, off = [], 0
+    for k, s in sizes:
+        flags = (0 if oo.is_no_decay(k) else 1) | (2 if k.endswith(".w") else 0)
+        for b in range(off, off + s, 1 << 14):
+            seg.append((b, min(off + s, b + (1 << 14)), flags))
+        off += s
+    seg_t = dev(np.array(seg, np.int64))
+    for step in range(4):
+        grads = {k: r.standard_normal(s).astype(np.float32) for k, s in sizes}
+        lr = oo.warmup_linear_lr(step, 10, 1e-2)
+        t = step + 1
+        lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        g = dev(np.concatenate([grads[k] for k, _ in sizes]))
+        ops.adam_step(p, g, m, v, shadow, seg_t, len(seg), lr, lr_t, 0.9, 0.999, 1e-7, 0.01)
+        opt.step(params, grads)
+    ref = np.concatenate([params[k] for k, _ in sizes])
+    assert_close(host(p), ref, 2e-6, "adam params")
+    sh = host(shadow)
+    assert_close(sh[:1000], rounded(ref[:1000], torch.bfloat16), 1e-6, "bf16 shadow")
+    assert np.all(sh[1000:1101] == 0)  # no shadow for biases / LN
+
+
+def test_sqnorm_clip_cast_scale(ops):
+    r = rng(17)
+    g = r.standard_normal(100003).astype(np.float32)
+    g_t = dev(g)[:100003]
+    sq = torch.empty(1, device="cuda")
+    ops.sqnorm(g_t, sq)
+    assert abs(float(sq) - float((g.astype(np.float64) ** 2).sum())) < 1e-3 * float(sq)
+    sc = torch.empty(1, device="cuda")
+    ops.clip_scale(sq, 0.5, 1.0, sc)
+    norm = math.sqrt(float((g.astype(np.float64) ** 2).sum())) * 0.5
+    assert abs(float(sc) - 1.0 / max(norm, 1.0)) < 1e-6
+    b = torch.empty(100003, dtype=torch.bfloat16, device="cuda")
+    ops.cast(g_t, b)
+    assert torch.equal(b, g_t.to(torch.bfloat16))
+    ops.scale_(g_t, 0.25)
+    assert_close(host(g_t), g * 0.25, 1e-7, "scale")
