@@ -171,6 +171,9 @@ int polus_sqnorm(const float* g, int64_t n, float* out, void* workspace, size_t 
 int polus_clip_scale(const float* sqnorm, float grad_scale, float clip_norm, float* out_scale, void* stream);
 /* f32 -> bf16 copy (shadow weights refresh after load / broadcast) and bf16/f32 casts */
 int polus_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* du = dy * act'(u) elementwise (activation gradient of a Dense whose dY is not produced by
+ * a polus_gemm epilogue) */
+int polus_act_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, int act, void* stream);
 /* y = a*x elementwise, f32 (gradient averaging when the comm backend lacks AVG) */
 int polus_scale(float* x, float a, int64_t n, void* stream);
 

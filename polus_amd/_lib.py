@@ -53,6 +53,7 @@ SIGNATURES = {
     "polus_clip_scale": (_i, [_vp, _f, _f, _vp, _vp]),
     "polus_cast": (_i, [_i, _vp, _i, _vp, _i64, _vp]),
     "polus_scale": (_i, [_vp, _f, _i64, _vp]),
+    "polus_act_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i, _vp]),
 }
 
 

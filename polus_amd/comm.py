@@ -1,0 +1,181 @@
+"""Data-parallel communication for the Polus step: RCCL over xGMI through torch.distributed.
+
+Replaces the six Horovod touch points of the reference (polus/mock/horovod.py:5-24 lists the
+surface; call sites polus/__init__.py:109-122, polus/training.py:182,210-211,
+polus/callbacks.py:249): one process per GPU launched by torchrun, backend "nccl" (= RCCL on
+ROCm) when a GPU is visible, "gloo" for the CPU multi-process tests.
+
+Horovod's DistributedGradientTape averages every gradient tensor with one all-reduce per
+tensor fused by a background thread.  Here the gradients already live in one flat f32 arena
+laid out in forward order, so the reducer cuts it into contiguous buckets from the END (the
+order backward produces them) and issues one all-reduce (SUM) per bucket as soon as the
+model reports the bucket's lowest tensor final; RCCL runs it on the process group's own
+stream beside the remaining backward kernels.  The 1/world factor is folded into the
+optimizer's gradient scale instead of a separate pass.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+_STATE = {"initialized": False, "world": 1, "rank": 0, "local_rank": 0, "backend": None}
+
+
+def _env_int(name, default):
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+def init():
+    """hvd.init(): joins the torchrun rendezvous when WORLD_SIZE > 1; otherwise the
+    world_size-1 behaviour of polus/mock/horovod.py ("mock")."""
+    if _STATE["initialized"]:
+        return _STATE["backend"] or "mock"
+    world = _env_int("WORLD_SIZE", 1)
+    _STATE["initialized"] = True
+    if world <= 1:
+        return "mock"
+    rank, local_rank = _env_int("RANK", 0), _env_int("LOCAL_RANK", 0)
+    use_gpu = torch.cuda.is_available()
+    backend = "nccl" if use_gpu else "gloo"
+    if use_gpu:
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if use_gpu:
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    _STATE.update(world=dist.get_world_size(), rank=dist.get_rank(), local_rank=local_rank, backend=backend)
+    return backend
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    _STATE.update(initialized=False, world=1, rank=0, local_rank=0, backend=None)
+
+
+def size():
+    return _STATE["world"]
+
+
+def rank():
+    return _STATE["rank"]
+
+
+def local_rank():
+    """The reference shards data and gates rank-0 side effects on local_rank()
+    (polus/data.py:96, polus/callbacks.py:27) — single-node semantics, kept."""
+    return _STATE["local_rank"]
+
+
+def is_distributed():
+    return _STATE["world"] > 1
+
+
+def DistributedGradientTape(tape):
+    """API-compat shim: there is no tape; gradient averaging is done by GradBucketReducer."""
+    return tape
+
+
+def _flat_tensors(variables):
+    """Variables of one arena -> [arena.params]; raw tensors pass through."""
+    out, seen = [], set()
+    for v in variables:
+        if hasattr(v, "arena"):
+            if id(v.arena) not in seen:
+                seen.add(id(v.arena))
+                out.append(("arena", v.arena))
+        else:
+            out.append(("tensor", v))
+    return out
+
+
+def broadcast_variables(variables, root_rank=0):
+    """hvd.broadcast_variables: one flat broadcast per arena (437.9 MB for BERT-base)
+    instead of one per variable; refreshes the bf16 shadow afterwards."""
+    if not is_distributed():
+        return
+    for kind, obj in _flat_tensors(variables):
+        if kind == "arena":
+            dist.broadcast(obj.params, src=root_rank)
+            obj.refresh_shadow()
+        else:
+            dist.broadcast(obj, src=root_rank)
+
+
+def allgather_object(y):
+    """hvd.allgather_object (polus/callbacks.py:249): list with one entry per rank."""
+    if not is_distributed():
+        return [y]
+    out = [None] * size()
+    if torch.is_tensor(y):
+        y = y.detach().cpu()
+    elif isinstance(y, (tuple, list)):
+        y = type(y)(t.detach().cpu() if torch.is_tensor(t) else t for t in y)
+    dist.all_gather_object(out, y)
+    return out
+
+
+def barrier():
+    if is_distributed():
+        dist.barrier()
+
+
+class GradBucketReducer:
+    """Bucketed, backward-overlapped gradient all-reduce over a flat arena."""
+
+    def __init__(self, grads, bucket_bytes=64 << 20, boundaries=None):
+        self.grads = grads
+        n = grads.numel()
+        elems = max(1, bucket_bytes // grads.element_size())
+        # cut at tensor boundaries when given (sorted offsets), from the end of the arena
+        cuts = sorted(set(boundaries or [])) or list(range(0, n, elems))
+        cuts = [c for c in cuts if 0 <= c < n]
+        if not cuts or cuts[0] != 0:
+            cuts = [0] + cuts
+        buckets, hi = [], n
+        lo_idx = len(cuts) - 1
+        while hi > 0:
+            lo = cuts[lo_idx]
+            while lo_idx > 0 and hi - cuts[lo_idx - 1] <= elems:
+                lo_idx -= 1
+                lo = cuts[lo_idx]
+            buckets.append((lo, hi))
+            hi = lo
+            lo_idx -= 1
+        self.buckets = buckets          # descending offsets
+        self._next = 0
+        self._ready_lo = n
+        self._works = []
+        self.launched_bytes = 0
+
+    def begin(self):
+        self._next, self._ready_lo, self._works = 0, self.grads.numel(), []
+
+    def on_ready(self, lo, hi):
+        """Model hook: grads[lo:hi] are final (called in descending arena order)."""
+        self._ready_lo = min(self._ready_lo, lo)
+        self._launch_ready()
+
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next][0] >= self._ready_lo:
+            lo, hi = self.buckets[self._next]
+            view = self.grads[lo:hi]
+            # async: the process group's stream waits for the kernels queued so far on the
+            # current stream, then reduces beside whatever backward launches next
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            self.launched_bytes += view.numel() * view.element_size()
+            self._next += 1
+
+    def finish(self):
+        """Flush what is left and make the current stream wait for every bucket."""
+        self._ready_lo = 0
+        self._launch_ready()
+        for w in self._works:
+            w.wait()
+        self._works = []

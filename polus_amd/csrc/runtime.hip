@@ -59,6 +59,24 @@ __global__ void scale_kernel(float* __restrict__ x, float a, int64_t n) {
     }
 }
 
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u, T* __restrict__ du, int64_t n, int act) {
+    int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i4 < n; i4 += stride) {
+        if (i4 + 4 <= n) {
+            float a[4], b[4];
+            load4<T>(dy + i4, a);
+            load4<T>(u + i4, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] *= apply_act_grad(act, b[e]);
+            store4<T>(du + i4, a);
+        } else {
+            for (int64_t j = i4; j < n; ++j) du[j] = from_f<T>(to_f<T>(dy[j]) * apply_act_grad(act, to_f<T>(u[j])));
+        }
+    }
+}
+
 inline int stream_grid(int64_t n) {
     int64_t b = (n / 4 + 255) / 256;
     if (b < 1) b = 1;
@@ -95,5 +113,21 @@ extern "C" int polus_scale(float* x, float a, int64_t n, void* stream) {
     POLUS_REQUIRE(((uintptr_t)x % 16) == 0, "polus_scale: pointer must be 16-byte aligned");
     hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, a, n);
     POLUS_CHECK_LAUNCH("polus_scale");
+    return POLUS_OK;
+}
+
+extern "C" int polus_act_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, int act, void* stream) {
+    POLUS_REQUIRE(dy && u && du && n >= 0, "polus_act_bwd: bad arguments");
+    if (n == 0) return POLUS_OK;
+    size_t es = polus_dtype_size(dtype);
+    POLUS_REQUIRE(((uintptr_t)dy % (4 * es)) == 0 && ((uintptr_t)u % (4 * es)) == 0 && ((uintptr_t)du % (4 * es)) == 0,
+                  "polus_act_bwd: pointers must be 4-element aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == POLUS_BF16)
+        hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(stream_grid(n)), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)du, n, act);
+    else if (dtype == POLUS_F32)
+        hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, st, (const float*)dy, (const float*)u, (float*)du, n, act);
+    else POLUS_FAIL("polus_act_bwd: bad dtype");
+    POLUS_CHECK_LAUNCH("polus_act_bwd");
     return POLUS_OK;
 }

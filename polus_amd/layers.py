@@ -1,0 +1,257 @@
+"""Layers with explicit forward/backward (no autograd, no tape): every backward is a fixed
+sequence of HIP launches, which is what lets the gradient all-reduce start the moment a
+layer's last dW kernel is queued.
+
+Mirrors the Keras layers the reference composes (tutorials/classifier_example.py:44-48,
+polus/ner/models.py:35-39) and polus/layers.py CRF.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+from . import ops
+from .tensor import DeviceScalar, to_device
+
+
+class Layer:
+    """forward(x, training) -> y ; backward(dy) -> dx ; variables() -> [Variable]."""
+    name = "layer"
+
+    def build(self, arena, in_features, prefix):
+        return in_features
+
+    def variables(self):
+        return []
+
+    def forward(self, x, training=False):
+        raise NotImplementedError
+
+    def backward(self, dy, accumulate=False):
+        raise NotImplementedError
+
+    def _buf(self, key, shape, dtype, dev):
+        cache = self.__dict__.setdefault("_bufs", {})
+        t = cache.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype:
+            t = cache[key] = torch.empty(tuple(shape), dtype=dtype, device=dev)
+        return t
+
+
+def dw_split_k(out_rows, out_cols, contraction):
+    """Split-K factor for dW = dY^T X: few output tiles, long contraction. Aim at >= ~2
+    workgroups per CU while keeping >= 256 contraction rows per slice."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    want = max(1, 768 // max(tiles, 1))
+    return int(max(1, min(want, contraction // 256, 64)))
+
+
+def glorot_uniform(rng, fan_in, fan_out, shape):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+class Flatten(Layer):
+    """tf.keras.layers.Flatten: [B, ...] -> [B, prod]."""
+
+    def __init__(self, input_shape=None):
+        self.input_shape = input_shape
+
+    def build(self, arena, in_features, prefix):
+        if self.input_shape is not None:
+            return int(np.prod(self.input_shape))
+        return in_features
+
+    def forward(self, x, training=False):
+        self._shape = x.shape
+        return x.reshape(x.shape[0], -1)
+
+    def backward(self, dy, accumulate=False):
+        return dy.reshape(self._shape)
+
+
+class Dropout(Layer):
+    """Inverted dropout. rate 0 (the parity configuration) is the identity."""
+
+    def __init__(self, rate=0.0, input_shape=None):
+        self.rate = float(rate)
+        if self.rate != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented in this round (see DESIGN.md, out of scope)")
+
+    def forward(self, x, training=False):
+        return x
+
+    def backward(self, dy, accumulate=False):
+        return dy
+
+
+class Dense(Layer):
+    """Keras Dense: y = act(x W^T + b), W stored [out, in].  out_dtype=float32 makes the
+    layer emit f32 (logits feeding a loss)."""
+
+    def __init__(self, units, activation=None, input_shape=None, use_bias=True, out_dtype=None, name=None):
+        self.units = int(units)
+        self.activation = activation if activation not in ("linear",) else None
+        self.input_shape = input_shape
+        self.use_bias = use_bias
+        self.out_dtype = out_dtype
+        self.name = name or "dense"
+
+    def build(self, arena, in_features, prefix):
+        if in_features is None:
+            in_features = self.input_shape[-1]
+        self.in_features = int(in_features)
+        rng = np.random.Generator(np.random.PCG64(zlib.crc32(f"{prefix}:{self.units}:{self.in_features}".encode())))
+        self.w = arena.add(prefix + ".w", (self.units, self.in_features),
+                           glorot_uniform(rng, self.in_features, self.units, (self.units, self.in_features)),
+                           decay=True, matrix=True)
+        self.b = arena.add(prefix + ".b", (self.units,), np.zeros(self.units, np.float32), decay=False) if self.use_bias else None
+        self.arena = arena
+        return self.units
+
+    def variables(self):
+        return [self.w] + ([self.b] if self.b is not None else [])
+
+    def forward(self, x, training=False):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        assert x2.shape[1] == self.in_features, f"{self.name}: expected {self.in_features} features, got {x2.shape[1]}"
+        rows = x2.shape[0]
+        odt = self.out_dtype or x2.dtype
+        y = self._buf("y", (rows, self.units), odt, x2.device)
+        bias = self.b.value if self.b is not None else None
+        if self.activation:
+            assert odt == x2.dtype, "an activated Dense keeps the compute dtype"
+            u = self._buf("u", (rows, self.units), x2.dtype, x2.device)
+            ops.gemm(x2, self.w.compute, y, bias=bias, aux=u, act=self.activation, flags=ops.GEMM_ACT_FWD)
+            self._u = u
+        else:
+            ops.gemm(x2, self.w.compute, y, bias=bias)
+        self._x = x2
+        return y.view(*lead, self.units)
+
+    def backward(self, dy, accumulate=False, need_dx=True):
+        x = self._x
+        dy2 = dy.reshape(-1, self.units)
+        if dy2.dtype != x.dtype:  # f32 dlogits of an f32-output layer in bf16 mode
+            d = self._buf("dy_cast", dy2.shape, x.dtype, x.device)
+            ops.cast(dy2.contiguous(), d)
+            dy2 = d
+        if self.activation:
+            du = self._buf("du", dy2.shape, x.dtype, x.device)
+            ops.act_bwd(dy2.contiguous(), self._u, du, self.activation)
+            dy2 = du
+        rows = x.shape[0]
+        acc = ops.GEMM_ACCUM_C if accumulate else 0
+        ops.gemm(dy2, x, self.w.grad, a_layout=ops.K_STRIDED, b_layout=ops.K_STRIDED, flags=acc,
+                 split_k=dw_split_k(self.units, self.in_features, rows))
+        if self.b is not None:
+            ops.colsum(dy2, self.b.grad, accumulate=accumulate)
+        if not need_dx:
+            return None
+        dx = self._buf("dx", (rows, self.in_features), x.dtype, x.device)
+        ops.gemm(dy2, self.w.compute, dx, b_layout=ops.K_STRIDED)
+        return dx
+
+
+class CRF(Layer):
+    """polus/layers.py:6-140.  Training: passes the potentials through and remembers the
+    sequence lengths (full S when none are given, :74-76); inference: Viterbi decode to
+    one-hot (:78-84).  `loss` / `loss_sample_weights` build the NLL of :86-126."""
+
+    def __init__(self, output_dim, sparse_target=True, mask_impossible_transitions=None, name="crf"):
+        self.output_dim = int(output_dim)
+        self.mask_impossible_transitions = mask_impossible_transitions
+        self.sequence_lengths = None
+        self.name = name
+
+    def build(self, arena, in_features, prefix):
+        if in_features != self.output_dim:
+            raise ValueError("The last dimension of the input shape must be equal to output shape. "
+                             "Use a linear layer if needed.")
+        C = self.output_dim
+        rng = np.random.Generator(np.random.PCG64(77 + C))
+        self.transitions = arena.add(prefix + ".transitions", (C, C), glorot_uniform(rng, C, C, (C, C)), decay=True)
+        self.arena = arena
+        return C
+
+    def variables(self):
+        return [self.transitions]
+
+    def get_transitions(self):
+        """polus/layers.py:58-63 — T*M + (1-M)*-10000; a tiny [C,C] host-side parameter
+        transform re-uploaded per step (C <= 16)."""
+        t = self.transitions.value
+        if self.mask_impossible_transitions is None:
+            return t
+        m = to_device(np.asarray(self.mask_impossible_transitions, np.float32), torch.float32, t.device)
+        return t * m + (1.0 - m) * -10000.0
+
+    def forward(self, x, training=False, sequence_lengths=None):
+        assert x.dim() == 3 and x.shape[-1] == self.output_dim
+        B, S, C = x.shape
+        if sequence_lengths is not None:
+            sl = to_device(sequence_lengths, torch.int32, x.device).reshape(-1)
+        else:
+            sl = torch.full((B,), S, dtype=torch.int32, device=x.device)
+        self.sequence_lengths = sl
+        self._pot = x
+        if training:
+            return x
+        tags = self._buf("tags", (B, S), torch.int32, x.device)
+        ops.crf_viterbi(x.float().contiguous() if x.dtype != torch.float32 else x.contiguous(), sl,
+                        self.get_transitions().contiguous(), tags)
+        return torch.nn.functional.one_hot(tags.long(), C).to(torch.float32)
+
+    def backward(self, dy, accumulate=False):
+        return dy
+
+    def _nll(self, y_true, y_pred, sample_weights):
+        pot = y_pred if y_pred.dtype == torch.float32 else y_pred.float()
+        pot = pot.contiguous()
+        B, S, C = pot.shape
+        yt = to_device(y_true, None, pot.device)
+        tags = (yt.argmax(-1) if yt.dim() == 3 else yt).to(torch.int32).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=pot.device)
+        dpot = self._buf("dpot", (B, S, C), torch.float32, pot.device)
+        dtr = self._buf("dtrans", (C, C), torch.float32, pot.device)
+        ops.crf_nll(pot, tags, self.sequence_lengths, self.get_transitions().contiguous(), sample_weights, loss, dpot, dtr)
+        if self.mask_impossible_transitions is not None:
+            dtr = dtr * to_device(np.asarray(self.mask_impossible_transitions, np.float32), torch.float32, pot.device)
+        self._dtrans, self._dpot = dtr, dpot
+        return DeviceScalar(loss)
+
+    @property
+    def loss(self):
+        layer = self
+
+        class _CRFLoss:
+            def __call__(self, y_true, y_pred):
+                return layer._nll(y_true, y_pred, None)
+
+            def backward(self, accumulate=False):
+                g = layer.transitions.grad
+                g.add_(layer._dtrans) if accumulate else g.copy_(layer._dtrans)
+                return layer._dpot
+        return _CRFLoss()
+
+    def loss_sample_weights(self, mask_positive_classes, negative_weight):
+        """polus/layers.py:101-126: per-sequence weight 1 if any positive class occurs else
+        negative_weight (computed on the labels, host side of the step)."""
+        layer = self
+        mpc = np.asarray(mask_positive_classes, np.float32)
+
+        class _CRFWLoss:
+            def __call__(self, y_true, y_pred):
+                yt = to_device(y_true, torch.float32, y_pred.device)
+                pos = yt * to_device(mpc, torch.float32, yt.device)
+                neg = (pos == 0).all(-1).all(-1)
+                w = (pos == 1).any(-1).any(-1).to(torch.float32) + neg.to(torch.float32) * float(negative_weight)
+                return layer._nll(y_true, y_pred, w.contiguous())
+
+            def backward(self, accumulate=False):
+                g = layer.transitions.grad
+                g.add_(layer._dtrans) if accumulate else g.copy_(layer._dtrans)
+                return layer._dpot
+        return _CRFWLoss()

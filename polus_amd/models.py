@@ -1,0 +1,476 @@
+"""Models of the Polus hot path on MI355X: the BERT encoder with explicit forward/backward
+over HIP kernels, the Keras-like Sequential wrappers, and the reference's model helpers.
+
+Mirrors polus/models.py: PolusModel / SavableModel / PolusClassifier (:85-154),
+TFBertSplited (:164-216), split_bert_model (:242-295).  The HuggingFace TFBertModel the
+reference loads (polus/models.py:225-229) is replaced by `BertModel` below: same
+architecture, weights in PyTorch [out, in] layout with Q/K/V fused
+into one [3H, H] matrix.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .layers import CRF, Dense, Dropout, Flatten, Layer, dw_split_k
+from .tensor import ParamArena, to_device, device
+
+COMPUTE_DTYPES = {"f32": torch.float32, "float32": torch.float32, torch.float32: torch.float32,
+                  "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, torch.bfloat16: torch.bfloat16}
+
+
+class BertConfig:
+    """Hyper-parameters of HF BertConfig that the encoder math depends on."""
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2, layer_norm_eps=1e-12,
+                 hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, _name_or_path=""):
+        if hidden_size != num_attention_heads * 64:
+            raise ValueError("the fused attention kernel is built for head_dim 64 (BERT-base/large, BioBERT, PubMedBERT)")
+        if hidden_dropout_prob or attention_probs_dropout_prob:
+            raise NotImplementedError("dropout > 0 is not implemented in this round (DESIGN.md, out of scope)")
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
+        self.type_vocab_size, self.layer_norm_eps = type_vocab_size, layer_norm_eps
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
+        self._name_or_path = _name_or_path
+
+    @classmethod
+    def bert_base(cls, **kw):
+        return cls(**kw)
+
+    @classmethod
+    def bert_large(cls, **kw):
+        return cls(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, **kw)
+
+    def to_dict(self):
+        return {k: v for k, v in self.__dict__.items()}
+
+
+class BaseModelOutputWithPooling:
+    """Stand-in for transformers' TFBaseModelOutputWithPooling (polus/models.py:215)."""
+
+    def __init__(self, last_hidden_state, pooler_output):
+        self.last_hidden_state, self.pooler_output = last_hidden_state, pooler_output
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return (self.last_hidden_state, self.pooler_output)[k]
+        return getattr(self, k)
+
+
+def _trunc_normal(rng, shape, std=0.02):
+    return (np.clip(rng.standard_normal(shape), -2.0, 2.0) * std).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------ BERT pieces
+class BertLayer:
+    """One post-LN transformer block: 4 MFMA GEMMs + fused attention + 2 LayerNorms forward,
+    8 GEMMs + 2 attention-backward kernels + 2 LN-backward backward."""
+
+    def __init__(self, cfg, arena, index, rng):
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        self.cfg, self.index = cfg, index
+        p = f"layer{index}."
+        add = arena.add
+        self.qkv_w = add(p + "qkv.w", (3 * H, H), _trunc_normal(rng, (3 * H, H)), matrix=True)
+        self.qkv_b = add(p + "qkv.b", (3 * H,), np.zeros(3 * H, np.float32), decay=False)
+        self.out_w = add(p + "out.w", (H, H), _trunc_normal(rng, (H, H)), matrix=True)
+        self.out_b = add(p + "out.b", (H,), np.zeros(H, np.float32), decay=False)
+        self.ln1_g = add(p + "ln1.g", (H,), np.ones(H, np.float32), decay=False)
+        self.ln1_b = add(p + "ln1.b", (H,), np.zeros(H, np.float32), decay=False)
+        self.ffn1_w = add(p + "ffn1.w", (I, H), _trunc_normal(rng, (I, H)), matrix=True)
+        self.ffn1_b = add(p + "ffn1.b", (I,), np.zeros(I, np.float32), decay=False)
+        self.ffn2_w = add(p + "ffn2.w", (H, I), _trunc_normal(rng, (H, I)), matrix=True)
+        self.ffn2_b = add(p + "ffn2.b", (H,), np.zeros(H, np.float32), decay=False)
+        self.ln2_g = add(p + "ln2.g", (H,), np.ones(H, np.float32), decay=False)
+        self.ln2_b = add(p + "ln2.b", (H,), np.zeros(H, np.float32), decay=False)
+        self._bufs = {}
+
+    def variables(self):
+        return [self.qkv_w, self.qkv_b, self.out_w, self.out_b, self.ln1_g, self.ln1_b,
+                self.ffn1_w, self.ffn1_b, self.ffn2_w, self.ffn2_b, self.ln2_g, self.ln2_b]
+
+    def _buf(self, key, shape, dtype, dev):
+        t = self._bufs.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype:
+            t = self._bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=dev)
+        return t
+
+    def forward(self, x, mask, B, S):
+        cfg = self.cfg
+        H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+        T, dt, dev = B * S, x.dtype, x.device
+        b = lambda k, shape, d=dt: self._buf(k, shape, d, dev)
+        qkv, ctx, lse = b("qkv", (T, 3 * H)), b("ctx", (T, H)), b("lse", (B, A, S), torch.float32)
+        z1, a1 = b("z1", (T, H)), b("a1", (T, H))
+        m1, r1 = b("m1", (T,), torch.float32), b("r1", (T,), torch.float32)
+        u, f = b("u", (T, I)), b("f", (T, I))
+        z2, y = b("z2", (T, H)), b("y", (T, H))
+        m2, r2 = b("m2", (T,), torch.float32), b("r2", (T,), torch.float32)
+        ops.gemm(x, self.qkv_w.compute, qkv, bias=self.qkv_b.value)
+        ops.attention_fwd(qkv, mask, ctx, lse, B, S, A)
+        ops.gemm(ctx, self.out_w.compute, z1, bias=self.out_b.value, resid=x)
+        ops.layernorm_fwd(z1, self.ln1_g.value, self.ln1_b.value, a1, m1, r1, cfg.layer_norm_eps)
+        ops.gemm(a1, self.ffn1_w.compute, f, bias=self.ffn1_b.value, aux=u, act="gelu", flags=ops.GEMM_ACT_FWD)
+        ops.gemm(f, self.ffn2_w.compute, z2, bias=self.ffn2_b.value, resid=a1)
+        ops.layernorm_fwd(z2, self.ln2_g.value, self.ln2_b.value, y, m2, r2, cfg.layer_norm_eps)
+        self._stash = (x, mask, B, S)
+        return y
+
+    def backward(self, dy, scratch, accumulate=False):
+        """dy [T,H] -> dx [T,H]; parameter gradients land in the arena (overwritten, or added
+        to when `accumulate`).  `scratch(key, shape)` hands out buffers shared by all layers."""
+        cfg = self.cfg
+        H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+        x, mask, B, S = self._stash
+        T = B * S
+        bb = self._bufs
+        acc = ops.GEMM_ACCUM_C if accumulate else 0
+        KS = ops.K_STRIDED
+        dz2, du = scratch("dz2", (T, H)), scratch("du", (T, I))
+        da1, dz1 = scratch("da1", (T, H)), scratch("dz1", (T, H))
+        dctx, dqkv = scratch("dctx", (T, H)), scratch("dqkv", (T, 3 * H))
+        dx = scratch("dx%d" % (self.index & 1), (T, H))
+        ops.layernorm_bwd(dy, bb["z2"], self.ln2_g.value, bb["m2"], bb["r2"], dz2,
+                          self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate)
+        ops.gemm(dz2, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, I, T))
+        ops.gemm(dz2, self.ffn2_w.compute, du, b_layout=KS, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
+        ops.colsum(du, self.ffn1_b.grad, accumulate)
+        ops.gemm(du, bb["a1"], self.ffn1_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(I, H, T))
+        ops.gemm(du, self.ffn1_w.compute, da1, b_layout=KS, resid=dz2)
+        ops.layernorm_bwd(da1, bb["z1"], self.ln1_g.value, bb["m1"], bb["r1"], dz1,
+                          self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate)
+        ops.gemm(dz1, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, H, T))
+        ops.gemm(dz1, self.out_w.compute, dctx, b_layout=KS)
+        ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A)
+        ops.colsum(dqkv, self.qkv_b.grad, accumulate)
+        ops.gemm(dqkv, x, self.qkv_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(3 * H, H, T))
+        ops.gemm(dqkv, self.qkv_w.compute, dx, b_layout=KS, resid=dz1)
+        return dx
+
+
+class BertEmbeddings:
+    def __init__(self, cfg, arena, rng):
+        H = cfg.hidden_size
+        self.cfg = cfg
+        self.word = arena.add("emb.word", (cfg.vocab_size, H), _trunc_normal(rng, (cfg.vocab_size, H)))
+        self.pos = arena.add("emb.pos", (cfg.max_position_embeddings, H), _trunc_normal(rng, (cfg.max_position_embeddings, H)))
+        self.type = arena.add("emb.type", (cfg.type_vocab_size, H), _trunc_normal(rng, (cfg.type_vocab_size, H)))
+        self.ln_g = arena.add("emb.ln.g", (H,), np.ones(H, np.float32), decay=False)
+        self.ln_b = arena.add("emb.ln.b", (H,), np.zeros(H, np.float32), decay=False)
+        self._bufs = {}
+
+    def variables(self):
+        return [self.word, self.pos, self.type, self.ln_g, self.ln_b]
+
+    def forward(self, input_ids, token_type_ids, dtype):
+        B, S = input_ids.shape
+        dev = input_ids.device
+        key = (B, S, dtype)
+        if self._bufs.get("key") != key:
+            self._bufs = {"key": key,
+                          "y": torch.empty((B * S, self.cfg.hidden_size), dtype=dtype, device=dev),
+                          "mean": torch.empty(B * S, dtype=torch.float32, device=dev),
+                          "rstd": torch.empty(B * S, dtype=torch.float32, device=dev)}
+        bb = self._bufs
+        ops.embed_ln_fwd(input_ids, token_type_ids, self.word.value, self.pos.value, self.type.value,
+                         self.ln_g.value, self.ln_b.value, bb["y"], bb["mean"], bb["rstd"], self.cfg.layer_norm_eps)
+        self._stash = (input_ids, token_type_ids)
+        return bb["y"]
+
+    def backward(self, dy, accumulate=False, deterministic=False):
+        ids, tts = self._stash
+        bb = self._bufs
+        ops.embed_ln_bwd(dy, ids, tts, self.word.value, self.pos.value, self.type.value, self.ln_g.value,
+                         bb["mean"], bb["rstd"], self.word.grad, self.pos.grad, self.type.grad,
+                         self.ln_g.grad, self.ln_b.grad, accumulate=accumulate, deterministic=deterministic)
+
+
+# ------------------------------------------------------------------------------------ model wrappers
+class PolusModel:
+    """polus/models.py:85-105.  Callable like a Keras model: ``model(x, training=False)`` or
+    ``model(**x, training=False)``; ``backward(dy)`` fills the gradient arena;
+    ``trainable_weights`` lists the Variables."""
+
+    def __init__(self, name=None):
+        self._name = name or self.__class__.__name__.lower()
+        self.grad_ready_hook = None   # called as hook(lo, hi) when grads[lo:hi] are final
+        self.deterministic = False
+        self.savable_config = {}
+
+    @property
+    def name(self):
+        return self._name
+
+    def set_name(self, name):
+        self._name = name
+
+    def init_from_data(self, *args, **kwargs):
+        self._init = (args, kwargs)
+        return self(*args, **kwargs)
+
+    @property
+    def trainable_weights(self):
+        return list(self.arena.vars)
+
+    def __call__(self, *args, training=False, **kwargs):
+        return self.call(*args, training=training, **kwargs)
+
+    def get_weights(self):
+        return [v.numpy() for v in self.trainable_weights]
+
+    def set_weights(self, weights):
+        for v, w in zip(self.trainable_weights, weights):
+            v.assign(w)
+
+    def _notify(self, variables):
+        if self.grad_ready_hook is not None and variables:
+            lo = min(v.offset for v in variables)
+            hi = max(v.offset + v.size for v in variables)
+            self.grad_ready_hook(lo, hi)
+
+
+class SavableModel(PolusModel):
+    """polus/models.py:107-133: <name><ext>.cfg (JSON config) + weights.  h5py is not in the
+    image: weights go to <name><ext>.npz with keys weight0..N in get_weights() order, the
+    same order the reference's .h5 datasets use."""
+
+    def save(self, base_path=os.path.join(".polus_cache", "saved_models"), extension=""):
+        os.makedirs(base_path, exist_ok=True)
+        path = os.path.join(base_path, self.name + extension)
+        with open(path + ".cfg", "w") as f:
+            json.dump(json.dumps(self.savable_config, default=str), f)
+        w = self.get_weights()
+        np.savez(path + ".npz", **{f"weight{i}": a for i, a in enumerate(w)})
+        return path
+
+
+class PolusClassifier(SavableModel):
+    def inference(self, x):
+        """polus/models.py:148-150: argmax over the last axis, int32."""
+        logits = self(x, training=False)
+        l2 = logits.reshape(-1, logits.shape[-1])
+        if l2.dtype != torch.float32:
+            l2 = l2.float()
+        out = torch.empty(l2.shape[0], dtype=torch.int32, device=l2.device)
+        ops.argmax(l2.contiguous(), out)
+        return out.view(logits.shape[:-1])
+
+
+class Sequential(PolusModel):
+    """tf.keras.Sequential over the layers of polus_amd.layers."""
+
+    def __init__(self, layers, compute_dtype="f32", name=None, input_dim=None):
+        super().__init__(name)
+        self.layers = list(layers)
+        self.compute_dtype = COMPUTE_DTYPES[compute_dtype]
+        self.arena = ParamArena(self.compute_dtype)
+        feat = input_dim
+        for i, l in enumerate(self.layers):
+            feat = l.build(self.arena, feat, f"{l.name}{i}")
+        # a classifier's last Dense feeds a loss: keep its logits in f32
+        last_dense = [l for l in self.layers if isinstance(l, Dense)]
+        if last_dense and last_dense[-1].activation is None and last_dense[-1].out_dtype is None:
+            last_dense[-1].out_dtype = torch.float32
+        self.arena.finalize()
+
+    def call(self, x, training=False, **kw):
+        x = to_device(x, None, self.arena.device)
+        if x.is_floating_point() and x.dtype != self.compute_dtype:
+            x = x.to(self.compute_dtype)
+        for l in self.layers:
+            x = l.forward(x, training=training)
+        return x
+
+    def backward(self, dy, accumulate=False):
+        first_param_layer = next(i for i, l in enumerate(self.layers) if l.variables())
+        for i in range(len(self.layers) - 1, -1, -1):
+            l = self.layers[i]
+            if isinstance(l, Dense):
+                dy = l.backward(dy, accumulate, need_dx=(i > first_param_layer))
+            else:
+                dy = l.backward(dy, accumulate)
+            self._notify(l.variables())
+            if dy is None:
+                break
+        return dy
+
+
+class SequentialSavableModel(Sequential, SavableModel):
+    pass
+
+
+class SequentialPolusClassifier(Sequential, PolusClassifier):
+    """polus/models.py:152-154 (tutorials/classifier_example.py:44-48)."""
+    pass
+
+
+class BertModel(PolusModel):
+    """Embeddings + encoder (+ optional token-level Dense head).  Input protocol of the HF
+    model the reference calls: input_ids, attention_mask, token_type_ids (int32 [B,S])."""
+
+    def __init__(self, cfg, compute_dtype="bf16", num_labels=None, seed=1234, name="bert", with_embeddings=True,
+                 layer_indices=None, arena=None):
+        super().__init__(name)
+        self.config = cfg
+        self.compute_dtype = COMPUTE_DTYPES[compute_dtype]
+        own = arena is None
+        self.arena = arena or ParamArena(self.compute_dtype)
+        rng = np.random.Generator(np.random.PCG64(seed))
+        self.embeddings = BertEmbeddings(cfg, self.arena, rng) if with_embeddings else None
+        idx = range(cfg.num_hidden_layers) if layer_indices is None else layer_indices
+        self.layer = [BertLayer(cfg, self.arena, i, rng) for i in idx]
+        self.head = None
+        if num_labels:
+            self.head = Dense(num_labels, out_dtype=torch.float32, name="head")
+            self.head.build(self.arena, cfg.hidden_size, "head")
+        if own:
+            self.arena.finalize()
+        self._scratch = {}
+
+    def scratch(self, key, shape):
+        t = self._scratch.get(key)
+        if t is None or t.shape != tuple(shape) or t.dtype != self.compute_dtype:
+            t = self._scratch[key] = torch.empty(tuple(shape), dtype=self.compute_dtype, device=self.arena.device)
+        return t
+
+    def load_numpy_params(self, params, head_w=None, head_b=None):
+        """params: dict in oracle/bert.py naming (emb.*, layer{i}.*)."""
+        for v in self.arena.vars:
+            if v.name in params:
+                v.assign(params[v.name])
+        if self.head is not None and head_w is not None:
+            self.head.w.assign(head_w)
+            self.head.b.assign(head_b)
+
+    def encode(self, hidden, attention_mask, B, S):
+        for l in self.layer:
+            hidden = l.forward(hidden, attention_mask, B, S)
+        return hidden
+
+    def call(self, input_ids=None, attention_mask=None, token_type_ids=None, training=False, hidden_states=None, **kw):
+        dev = self.arena.device
+        if isinstance(input_ids, dict):
+            d = input_ids
+            input_ids, attention_mask = d.get("input_ids"), d.get("attention_mask", attention_mask)
+            token_type_ids = d.get("token_type_ids", token_type_ids)
+        if attention_mask is not None:
+            attention_mask = to_device(attention_mask, torch.int32, dev)
+        if hidden_states is None:
+            input_ids = to_device(input_ids, torch.int32, dev)
+            B, S = input_ids.shape
+            if token_type_ids is not None:
+                token_type_ids = to_device(token_type_ids, torch.int32, dev)
+            hidden = self.embeddings.forward(input_ids, token_type_ids, self.compute_dtype)
+        else:
+            hs = to_device(hidden_states, self.compute_dtype, dev)
+            B, S = hs.shape[0], hs.shape[1]
+            hidden = hs.reshape(B * S, -1)
+        self._shape = (B, S)
+        hidden = self.encode(hidden, attention_mask, B, S)
+        H = self.config.hidden_size
+        if self.head is not None:
+            return self.head.forward(hidden).view(B, S, -1)
+        h3 = hidden.view(B, S, H)
+        return BaseModelOutputWithPooling(last_hidden_state=h3, pooler_output=h3[:, 0, :])
+
+    def backward(self, dy, accumulate=False):
+        """dy: gradient wrt the logits [B,S,C] (head) or wrt last_hidden_state [B,S,H]."""
+        B, S = self._shape
+        if self.head is not None:
+            dy = self.head.backward(dy.reshape(B * S, -1), accumulate)
+            self._notify(self.head.variables())
+        else:
+            dy = to_device(dy, self.compute_dtype, self.arena.device).reshape(B * S, -1)
+        for l in reversed(self.layer):
+            dy = l.backward(dy, self.scratch, accumulate)
+            self._notify(l.variables())
+        if self.embeddings is not None:
+            self.embeddings.backward(dy, accumulate, self.deterministic)
+            self._notify(self.embeddings.variables())
+            return None
+        return dy.view(B, S, -1)
+
+    def inference(self, x):
+        logits = self(**x, training=False) if isinstance(x, dict) else self(x, training=False)
+        l2 = logits.reshape(-1, logits.shape[-1]).contiguous()
+        out = torch.empty(l2.shape[0], dtype=torch.int32, device=l2.device)
+        ops.argmax(l2, out)
+        return out.view(logits.shape[:-1])
+
+
+class TFBertSplited(PolusModel):
+    """polus/models.py:164-216: runs a slice of encoder layers over given hidden states with
+    the (1-m)*-10000 mask (applied inside the attention kernel) and returns
+    pooler_output = hidden[:, 0, :] (no dense, no tanh).  Shares the layer objects — and so
+    the weights — of the model it was split from."""
+
+    def __init__(self, bert_layers, arena, config, run_in_training_mode=True, name="bert_splited"):
+        super().__init__(name)
+        self.layer = list(bert_layers)
+        self.arena, self.config = arena, config
+        self.run_in_training_mode = run_in_training_mode
+        self.compute_dtype = arena.compute_dtype
+        self._scratch = {}
+
+    scratch = BertModel.scratch
+
+    @property
+    def trainable_weights(self):
+        return [v for l in self.layer for v in l.variables()]
+
+    def call(self, hidden_states, attention_mask, training=False, **kw):
+        dev = self.arena.device
+        hs = to_device(hidden_states, self.compute_dtype, dev)
+        B, S, H = hs.shape
+        mask = to_device(attention_mask, torch.int32, dev)
+        hidden = hs.reshape(B * S, H)
+        for l in self.layer:
+            hidden = l.forward(hidden, mask, B, S)
+        self._shape = (B, S)
+        h3 = hidden.view(B, S, H)
+        return BaseModelOutputWithPooling(last_hidden_state=h3, pooler_output=h3[:, 0, :])
+
+    def backward(self, dy, accumulate=False):
+        B, S = self._shape
+        dy = to_device(dy, self.compute_dtype, self.arena.device).reshape(B * S, -1)
+        for l in reversed(self.layer):
+            dy = l.backward(dy, self.scratch, accumulate)
+            self._notify(l.variables())
+        return dy.view(B, S, -1)
+
+
+def split_bert_model(bert_model, index_layer, init_models=False, return_pre_bert_model=True,
+                     return_post_bert_model=True):
+    """polus/models.py:242-295: cut `bert_model` at `index_layer` (negative allowed,
+    != 0, |index| < L); the pre model keeps the embeddings and the first layers, the post model
+    (TFBertSplited) runs the remaining ones on the same weights."""
+    assert return_pre_bert_model or return_post_bert_model
+    L = bert_model.config.num_hidden_layers
+    assert L > index_layer > -L and index_layer != 0
+    post_model = None
+    if return_post_bert_model:
+        post_model = TFBertSplited(bert_model.layer[index_layer:], bert_model.arena, bert_model.config)
+    if return_pre_bert_model:
+        del bert_model.layer[index_layer:]
+        bert_model.config.num_hidden_layers = len(bert_model.layer)
+    if init_models and return_pre_bert_model:
+        B, S = 1, min(50, bert_model.config.max_position_embeddings)
+        ids = np.ones((B, S), np.int32)
+        out = bert_model(input_ids=ids, attention_mask=np.ones((B, S), np.int32), token_type_ids=np.zeros((B, S), np.int32))
+        if post_model is not None:
+            post_model(hidden_states=out.last_hidden_state, attention_mask=np.ones((B, S), np.int32))
+    if return_pre_bert_model and return_post_bert_model:
+        return bert_model, post_model
+    return bert_model if return_pre_bert_model else post_model
+
+
+def split_bert_model_from_checkpoint(bert_model_checkpoint, index_layer, **kw):
+    """polus/models.py:219-240 fetches the checkpoint by name from the HF hub; there is no
+    network here, so only a local directory holding config.json + *.safetensors is accepted."""
+    from .checkpoint import load_bert_from_local
+    return split_bert_model(load_bert_from_local(bert_model_checkpoint), index_layer, **kw)

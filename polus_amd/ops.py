@@ -254,3 +254,10 @@ def cast(src, dst):
 def scale_(x, a):
     _req_cuda(x)
     check(_lib.load().polus_scale(ptr(x), float(a), x.numel(), _st()), "polus_scale")
+
+
+def act_bwd(dy, u, du, act):
+    _req_cuda(dy, u, du)
+    assert dy.numel() == u.numel() == du.numel() and dy.is_contiguous() and u.is_contiguous() and du.is_contiguous()
+    check(_lib.load().polus_act_bwd(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(du), dy.numel(),
+                                    ACT_CODES[act] if not isinstance(act, int) else act, _st()), "polus_act_bwd")

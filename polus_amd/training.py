@@ -1,0 +1,232 @@
+"""Trainer drop-in for polus/training.py: BaseTrainer / ClassifierTrainer with the same
+constructor, attributes, hooks and training-loop order, over the MI355X engine.
+
+What changes underneath ``train_step`` (polus/training.py:150-193): the GradientTape is
+replaced by the models' explicit backward (HIP kernels), ``hvd.DistributedGradientTape`` by
+a bucketed RCCL all-reduce that starts while backward is still running, and
+``optimizer.apply_gradients`` by one fused multi-tensor launch.
+"""
+import os
+
+from . import comm
+from .callbacks import CallbackCoordinator, Profiler
+from .context import PolusContext, logger
+
+hvd = comm
+
+
+class BaseTrainer:
+    """polus/training.py:14-338."""
+
+    def __init__(self, model, optimizer, loss, metrics=[], post_process_logits=None, post_process_grads=None):
+        if self.__class__.__name__ == "BaseTrainer":
+            raise Exception("This is an abstraction that cannot be instantiated")
+        super().__init__()
+        self.model = model
+        self.loss = loss
+        self.optimizer = optimizer
+        self.post_process_logits = post_process_logits
+        self.post_process_grads = post_process_grads
+        self.metrics = metrics
+        self.early_stop = False
+        self.train_config = {}
+        self.step_counter = 0
+        self.grad_accum_steps = 1
+
+        if not hasattr(self, "trainable_weights"):
+            logger.warning(f"Since no specific trainable_weights were defined during the {self.__class__.__name__} "
+                           "instantiation, the trainer will optimizer all the variables found on the model instance")
+            self.trainable_weights = model.trainable_weights
+
+        self.use_horovod = PolusContext().is_horovod_enabled()
+        self._reducers = {}
+        if self.use_horovod:
+            # polus/training.py:90-94: learning rate x world size
+            if hasattr(optimizer, "learning_rate"):
+                optimizer.learning_rate.scale(hvd.size())
+                logger.info("The learning rate was adjusted to account for the multiGPU training")
+            else:
+                logger.info("It was not possible to change the learning rate for the multiGPU training, "
+                            "please multiply the learning rate by hvd.size()")
+
+    def __str__(self):
+        return "Trainer"
+
+    # ---- hooks (same contract as the reference)
+    def forward_without_grads(self, *inputs):
+        return inputs
+
+    def forward_with_grads(self, *inputs):
+        raise NotImplementedError("forward_with_grads function must be implemented in order to compute a loss "
+                                  "value for optimization")
+
+    def backward_from_loss(self, accumulate=False):
+        """The explicit counterpart of tape.gradient (polus/training.py:185): pull the
+        gradient of the loss wrt the model output and push it through the model."""
+        dlogits = self.loss.backward(accumulate)
+        self.model.backward(dlogits, accumulate=accumulate)
+
+    # ---- gradient exchange
+    def _arenas(self):
+        seen, out = set(), []
+        for v in self.trainable_weights:
+            if id(v.arena) not in seen:
+                seen.add(id(v.arena))
+                out.append(v.arena)
+        return out
+
+    def _reducer(self, arena):
+        r = self._reducers.get(id(arena))
+        if r is None:
+            bucket = int(os.environ.get("POLUS_BUCKET_MB", "64")) << 20
+            r = comm.GradBucketReducer(arena.grads, bucket_bytes=bucket,
+                                       boundaries=[v.offset for v in arena.vars])
+            self._reducers[id(arena)] = r
+        return r
+
+    def train_step(self, *inputs):
+        """polus/training.py:150-193, same order: forward_without_grads -> forward_with_grads
+        -> loss -> gradients (all-reduced across ranks) -> post_process_grads -> apply."""
+        micro = self.step_counter_micro = getattr(self, "step_counter_micro", 0)
+        accum = self.grad_accum_steps
+        first, last = (micro % accum == 0), (micro % accum == accum - 1)
+
+        inputs = self.forward_without_grads(*inputs)
+        inputs = self.forward_with_grads(*inputs)
+        loss_value = self.loss(*inputs)
+
+        reducers = []
+        if self.use_horovod and last:
+            arenas = self._arenas()
+            if len(arenas) == 1 and hasattr(self.model, "grad_ready_hook") and accum == 1:
+                r = self._reducer(arenas[0])
+                r.begin()
+                self.model.grad_ready_hook = r.on_ready
+                reducers = [r]
+        self.backward_from_loss(accumulate=not first)
+        self.step_counter_micro = micro + 1
+        if not last:
+            return loss_value
+
+        if self.use_horovod:
+            if not reducers:
+                reducers = [self._reducer(a) for a in self._arenas()]
+                for r in reducers:
+                    r.begin()
+            for r in reducers:
+                r.finish()
+            if hasattr(self.model, "grad_ready_hook"):
+                self.model.grad_ready_hook = None
+
+        # gradients hold the SUM over ranks and micro-steps; the mean is taken inside the
+        # fused optimizer kernel
+        scale = 1.0 / (hvd.size() * accum)
+        grads = [v.grad for v in self.trainable_weights]
+        if self.post_process_grads is not None:
+            if scale != 1.0:
+                from . import ops
+                for a in self._arenas():
+                    ops.scale_(a.grads, scale)
+                scale = 1.0
+            grads = self.post_process_grads(grads)
+        if hasattr(self.optimizer, "grad_scale"):
+            self.optimizer.grad_scale = scale
+        self.optimizer.apply_gradients(zip(grads, self.trainable_weights))
+        return loss_value
+
+    def lr_finder(self, tf_dataset, use_lr_found=False):
+        pass
+
+    def changing_train_config(self, **config):
+        for k, v in config.items():
+            self.train_config[k] = v
+
+    def broadcast_init_vars(self):
+        """polus/training.py:208-211."""
+        hvd.broadcast_variables(self.trainable_weights, root_rank=0)
+        hvd.broadcast_variables(self.optimizer.variables(), root_rank=0)
+
+    def train(self, tf_dataset=None, epochs=None, callbacks=[], train_map_f=None, steps=None, **kwargs):
+        """polus/training.py:213-338 — same hook order, including on_train_batch_begin firing
+        before the fetch (once extra at exhaustion) and the re-broadcast at step 0 of every
+        epoch."""
+        if tf_dataset is None:
+            if "tf_dataset" in self.train_config:
+                tf_dataset = self.train_config["tf_dataset"]
+            else:
+                raise ValueError("You need to pass a training dataset to the trainer.train method")
+        if epochs is None:
+            if "epochs" in self.train_config:
+                epochs = self.train_config["epochs"]
+            else:
+                raise ValueError("You need to pass the epochs variable to the trainer.train method")
+        if len(callbacks) == 0 and "callbacks" in self.train_config:
+            callbacks = self.train_config["callbacks"]
+        if train_map_f is None and "train_map_f" in self.train_config:
+            train_map_f = self.train_config["train_map_f"]
+        if steps is None and "steps" in self.train_config:
+            steps = self.train_config["steps"]
+
+        if steps is None:
+            try:
+                N_STEPS = len(tf_dataset)
+            except TypeError:
+                N_STEPS = -2  # tf.data UNKNOWN_CARDINALITY
+        else:
+            N_STEPS = steps
+
+        if "custom_data_transform_f" in kwargs:
+            train_map_f = kwargs.pop("custom_data_transform_f")
+
+        if os.getenv("POLUS_PROFILER", "False").lower() in ("true", "1", "t", "y", "yes"):
+            logger.info("POLUS_PROFILER env was set to True, so the Profiler callback was added to training")
+            profiler_step_range = list(map(int, os.getenv("POLUS_PROFILER_RANGE", "10:20").split(":")))
+            callbacks = list(callbacks) + [Profiler(steps_interval=profiler_step_range)]
+
+        if not isinstance(callbacks, CallbackCoordinator):
+            callbacks = CallbackCoordinator(callbacks, trainer=self, epochs=epochs, steps=N_STEPS)
+        self.callbacks = callbacks
+        self.callbacks.on_train_begin()
+
+        for epoch in range(epochs):
+            self.callbacks.on_epoch_begin(epoch)
+            _iter = iter(tf_dataset)
+            step = 0
+            while True:
+                self.callbacks.on_train_batch_begin(epoch, step)
+                data = next(_iter, None)
+                if data is None:
+                    break
+                if train_map_f is not None:
+                    data = train_map_f(data)
+                if step == 0 and self.use_horovod:
+                    self.broadcast_init_vars()
+                loss = self.train_step(*data)
+                self.callbacks.on_train_batch_end(epoch, step, loss)
+                self.step_counter += 1
+                step += 1
+                if self.early_stop:
+                    break
+            self.callbacks.on_epoch_end(epoch)
+            if self.early_stop:
+                break
+        self.callbacks.on_train_end()
+
+
+class ClassifierTrainer(BaseTrainer):
+    """polus/training.py:341-397."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+    def forward_with_grads(self, x, y):
+        if isinstance(x, dict):
+            logits = self.model(**x, training=True)
+        else:
+            logits = self.model(x, training=True)
+        if self.post_process_logits is not None:
+            logits = self.post_process_logits(logits)
+        return y, logits
+
+
+Trainer = ClassifierTrainer  # BASELINE.json's wording; the reference has no class of this name

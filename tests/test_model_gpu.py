@@ -1,0 +1,223 @@
+"""End-to-end parity of the HIP engine against the committed golden vectors
+(tests/golden/*.npz, produced by the PyTorch twin of the reference's HF TF-BERT) and against
+the CPU oracle: logits, loss, every parameter gradient, and a 5-step AdamW loss trajectory.
+
+Tolerances (stated per BASELINE.md §2): f32 engine — loss 2e-5 abs, logits/grads 1e-4 of
+max|ref|; bf16 engine — loss 2e-2 abs, logits 3e-2, gradients 6e-2 of max|ref| (bf16 storage
+of activations, f32 accumulation and f32 master weights)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bert as ob
+from oracle import losses as ol
+from oracle import optim as oo
+from tests.util import assert_close, dev, host, relerr
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = ["bert_small_b2_s16", "bert_small_b3_s48", "bert_base1_b2_s64"]
+TOLS = {"f32": dict(loss=2e-5, logits=1e-4, grad=2e-4), "bf16": dict(loss=2e-2, logits=3e-2, grad=6e-2)}
+
+
+def load_case(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    v, h, l, a, i, p, t = [int(x) for x in g["cfg"]]
+    ocfg = ob.BertConfig(v, h, l, a, i, p, t)
+    params, head_w, head_b = ob.golden_setup(ocfg, g["logits"].shape[-1])
+    chk = np.array([float(np.abs(params[k]).sum()) for k in sorted(params)])
+    assert np.allclose(chk, g["param_checksum"], rtol=1e-12), "seeded parameters differ from the golden run"
+    return g, ocfg, params, head_w, head_b
+
+
+def build_model(ocfg, params, head_w, head_b, mode):
+    from polus_amd.models import BertConfig, BertModel
+    cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                     ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size)
+    m = BertModel(cfg, compute_dtype=mode, num_labels=head_w.shape[0])
+    m.load_numpy_params(params, head_w, head_b)
+    return m
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES)
+def test_forward_backward_matches_golden(case, mode):
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    g, ocfg, params, head_w, head_b = load_case(case)
+    tol = TOLS[mode]
+    model = build_model(ocfg, params, head_w, head_b, mode)
+    loss_fn = SparseCategoricalCrossentropy(from_logits=True, grad_dtype=model.compute_dtype)
+    x = {"input_ids": g["ids"], "attention_mask": g["mask"], "token_type_ids": g["token_type"]}
+    logits = model(**x, training=True)
+    loss = loss_fn(g["labels"], logits)
+    assert abs(float(loss) - float(g["loss"])) < tol["loss"], (float(loss), float(g["loss"]))
+    assert_close(host(logits), g["logits"], tol["logits"], "logits")
+    model.backward(loss_fn.backward())
+    torch.cuda.synchronize()
+    got = {v.name: host(v.grad) for v in model.trainable_weights}
+    names = [str(n) for n in g["grad_names"]]
+    for k, norm, head in zip(names, g["grad_norms"], g["grad_heads"]):
+        a = got[k].reshape(-1)
+        # per-tensor L2 norm and the first 64 entries pinned by the golden file
+        assert abs(np.sqrt((a ** 2).sum()) - norm) <= tol["grad"] * max(norm, 1e-6) * 4, (k, np.sqrt((a ** 2).sum()), norm)
+        n = min(64, a.size)
+        scale = np.abs(got[k]).max() + 1e-30
+        assert np.abs(a[:n] - head[:n]).max() <= tol["grad"] * scale, (k, np.abs(a[:n] - head[:n]).max(), scale)
+    assert_close(got["head.w"], g["grad_head_w"], tol["grad"], "head.w grad")
+    # full-tensor check of every gradient against the float64 oracle
+    _, _, cache = ob.token_classifier_fwd(params, ocfg, head_w, head_b, g["ids"], g["mask"], g["labels"], g["token_type"])
+    og = ob.token_classifier_bwd(params, ocfg, head_w, cache)
+    for k, ref in og.items():
+        assert_close(got[k], ref, tol["grad"], f"grad {k}")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_adamw_trajectory_matches_golden(mode):
+    """5 optimisation steps (HF-twin gradients + Keras-Adam/AdamWeightDecay restatement in the
+    golden file) through ClassifierTrainer.train_step."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.schedulers import warmup_scheduler
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b2_s16")
+    steps = int(g["traj_steps"])
+    model = build_model(ocfg, params, head_w, head_b, mode)
+    opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps, 1e-3), weight_decay_rate=0.01)
+    trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy(grad_dtype=model.compute_dtype))
+    losses = []
+    for s in range(steps):
+        ids, mask, tt, labels = synth_batch(ocfg, 2, 16, 4, 42 + s)
+        loss = trainer.train_step({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels)
+        losses.append(float(loss))
+    ref = g["traj_loss"]
+    tol = 1e-4 if mode == "f32" else 3e-2
+    assert np.abs(np.array(losses) - ref).max() < tol, (losses, ref.tolist())
+
+
+def test_gradient_accumulation_equals_big_batch():
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b2_s16")
+    model = build_model(ocfg, params, head_w, head_b, "f32")
+    loss_fn = SparseCategoricalCrossentropy()
+    x = {"input_ids": g["ids"], "attention_mask": g["mask"], "token_type_ids": g["token_type"]}
+    loss_fn(g["labels"], model(**x, training=True)); model.backward(loss_fn.backward())
+    once = {v.name: host(v.grad) for v in model.trainable_weights}
+    loss_fn(g["labels"], model(**x, training=True)); model.backward(loss_fn.backward(), accumulate=True)
+    twice = {v.name: host(v.grad) for v in model.trainable_weights}
+    for k in once:
+        assert_close(twice[k], 2 * once[k], 1e-5, f"accumulate {k}")
+
+
+def test_deterministic_mode_is_bitwise_reproducible():
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b3_s48")
+    model = build_model(ocfg, params, head_w, head_b, "bf16")
+    model.deterministic = True
+    loss_fn = SparseCategoricalCrossentropy(grad_dtype=torch.bfloat16)
+    x = {"input_ids": g["ids"], "attention_mask": g["mask"], "token_type_ids": g["token_type"]}
+    runs = []
+    for _ in range(2):
+        loss_fn(g["labels"], model(**x, training=True)); model.backward(loss_fn.backward())
+        runs.append(model.arena.grads.clone())
+    assert torch.equal(runs[0], runs[1])
+
+
+def test_split_bert_model_equals_full_model():
+    """tests/test_models.py:6-67 of the reference, with a numeric comparator that can fail:
+    pre + post model == full model; pooler_output = hidden[:, 0, :]."""
+    from polus_amd.models import BertConfig, BertModel, split_bert_model
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b3_s48")
+    cfg = lambda: BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                             ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size)
+    full = BertModel(cfg(), compute_dtype="f32"); full.load_numpy_params(params)
+    x = {"input_ids": g["ids"], "attention_mask": g["mask"], "token_type_ids": g["token_type"]}
+    control = host(full(**x).last_hidden_state)
+    assert_close(control, g["last_hidden"], 1e-4, "last_hidden vs golden")
+    m2 = BertModel(cfg(), compute_dtype="f32"); m2.load_numpy_params(params)
+    pre, post = split_bert_model(m2, -1, init_models=True)
+    assert pre.config.num_hidden_layers == ocfg.num_hidden_layers - 1 and len(post.layer) == 1
+    hs = pre(**x).last_hidden_state
+    out = post(hidden_states=hs, attention_mask=g["mask"])
+    assert_close(host(out.last_hidden_state), control, 1e-5, "split == full")
+    assert torch.equal(out.pooler_output, out.last_hidden_state[:, 0, :])
+    assert out.pooler_output.shape == (3, ocfg.hidden_size)
+    with pytest.raises(AssertionError):
+        split_bert_model(BertModel(cfg(), compute_dtype="f32"), 0)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_mlp_classifier_step_matches_oracle(mode):
+    """configs[0]: the tutorial MLP 784 -> 128 (relu) -> 10 with Keras Adam(1e-3)
+    (tutorials/classifier_example.py:44-55), one ClassifierTrainer step vs NumPy."""
+    from polus_amd.layers import Dense, Flatten
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import SequentialPolusClassifier
+    from polus_amd.optimizers import Adam
+    from polus_amd.training import ClassifierTrainer
+    r = np.random.Generator(np.random.PCG64(5))
+    x = r.uniform(size=(128, 28, 28)).astype(np.float32)
+    y = r.integers(0, 10, size=128).astype(np.int32)
+    model = SequentialPolusClassifier([Flatten(input_shape=(28, 28)), Dense(128, activation="relu"), Dense(10)],
+                                      compute_dtype=mode, input_dim=784)
+    w = {v.name: v.numpy().astype(np.float64) for v in model.trainable_weights}
+    names = [v.name for v in model.trainable_weights]
+    trainer = ClassifierTrainer(model, Adam(1e-3), SparseCategoricalCrossentropy(grad_dtype=model.compute_dtype))
+    loss = float(trainer.train_step(x, y))
+    # oracle
+    w1, b1, w2, b2 = (w[n] for n in names)
+    xf = x.reshape(128, -1).astype(np.float64)
+    u = xf @ w1.T + b1
+    hdn = np.maximum(u, 0)
+    logits = hdn @ w2.T + b2
+    loss_ref, dlog = ol.sparse_softmax_xent_fwd(logits, y)
+    gw2, gb2 = dlog.T @ hdn, dlog.sum(0)
+    du = (dlog @ w2) * (u > 0)
+    grads = {names[0]: du.T @ xf, names[1]: du.sum(0), names[2]: gw2, names[3]: gb2}
+    opt = oo.Adam(lr=1e-3)
+    opt.step(w, grads)
+    tol = 1e-5 if mode == "f32" else 2e-2
+    assert abs(loss - loss_ref) < tol * 10
+    for n in names:
+        got = dict((v.name, v) for v in model.trainable_weights)[n]
+        assert_close(host(got.grad), grads[n], 1e-4 if mode == "f32" else 5e-2, f"grad {n}")
+        assert_close(got.numpy(), w[n], 1e-5 if mode == "f32" else 2e-3, f"updated {n}")
+    pred = model.inference(x)
+    assert pred.dtype == torch.int32 and pred.shape == (128,)
+
+
+def test_ner_mlp_crf_step_matches_oracle():
+    """polus/ner/models.py:26-44 head over precomputed 768-d embeddings with the CRF loss."""
+    from polus_amd.ner.models import baselineNER_MLP_CRF
+    B, S, C = 4, 24, 3
+    r = np.random.Generator(np.random.PCG64(9))
+    x = r.standard_normal((B, S, 768)).astype(np.float32)
+    tags = r.integers(0, C, size=(B, S))
+    y = np.eye(C, dtype=np.float32)[tags]
+    model = baselineNER_MLP_CRF(sequence_length=S, output_classes=C)
+    w = {v.name: v.numpy().astype(np.float64) for v in model.trainable_weights}
+    n = [v.name for v in model.trainable_weights]
+    pot = model(x, training=True)
+    loss = float(model.loss(y, pot))
+    u = x.reshape(-1, 768).astype(np.float64) @ w[n[0]].T + w[n[1]]
+    hdn = ob.swish(u)
+    pot_ref = (hdn @ w[n[2]].T + w[n[3]]).reshape(B, S, C)
+    assert_close(host(pot), pot_ref, 1e-4, "potentials")
+    loss_ref, dpot, dT = ol.crf_nll_fwd(y, pot_ref, np.full(B, S), w[n[4]])
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    loss_obj = model.loss
+    loss_obj(y, pot)
+    model.backward(loss_obj.backward())
+    got = {v.name: host(v.grad) for v in model.trainable_weights}
+    assert_close(got[n[4]], dT, 2e-4, "transitions grad")
+    d2 = dpot.reshape(-1, C)
+    assert_close(got[n[2]], d2.T @ hdn, 2e-4, "dense2 grad")
+    du = (d2 @ w[n[2]]) * ob.swish_grad(u)
+    assert_close(got[n[0]], du.T @ x.reshape(-1, 768), 2e-4, "dense1 grad")
+    dec = model(x, training=False)
+    assert dec.shape == (B, S, C)
+    ref_tags = ol.crf_viterbi(pot_ref, np.full(B, S), w[n[4]])
+    assert np.array_equal(model.inference(x).cpu().numpy(), ref_tags)
