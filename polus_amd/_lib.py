@@ -74,6 +74,13 @@ def load():
         raise PolusHipError(
             f"{path} is missing: build it with `python -m polus_amd.build` "
             "(or __graft_entry__.build()). There is no CPU fallback for the training path.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  Load torch's copy first so this library binds to the runtime that owns
+    # torch's allocations and streams; loading ours first would start a second runtime.
+    import torch
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = ABI mismatch, fail loudly

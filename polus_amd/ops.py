@@ -9,6 +9,9 @@ from . import _lib
 from ._lib import (F32, BF16, K_CONTIG, K_STRIDED, ACT_NONE, ACT_GELU, ACT_SWISH, ACT_RELU, ACT_TANH,
                    GEMM_ACCUM_C, GEMM_ACT_FWD, GEMM_ACT_BWD, check, ptr, dtype_code)
 
+# bench.py instrumentation: when a list, every gemm launch appends (kind, flops, ev0, ev1)
+GEMM_PROFILE = None
+
 ACT_CODES = {None: ACT_NONE, "linear": ACT_NONE, "gelu": ACT_GELU, "swish": ACT_SWISH,
              "relu": ACT_RELU, "tanh": ACT_TANH}
 
@@ -78,6 +81,10 @@ def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=N
     if split_k > 1:
         ws_bytes = lib.polus_gemm_workspace_bytes(M, N, split_k)
         ws = workspace(a.device).get(ws_bytes)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.polus_gemm(dt, a_layout, b_layout, dtype_code(out.dtype),
                          ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
                          M, N, K, float(alpha), ptr(bias),
@@ -85,6 +92,10 @@ def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=N
                          ptr(aux), aux.stride(0) if aux is not None else 0,
                          ACT_CODES[act] if not isinstance(act, int) else act, flags, split_k,
                          ptr(ws), ws_bytes, _st()), "polus_gemm")
+    if prof is not None:
+        e1.record()
+        kind = "fwd" if (a_layout == K_CONTIG and b_layout == K_CONTIG) else ("dx" if a_layout == K_CONTIG else "dw")
+        prof.append((kind, 2.0 * M * N * K, e0, e1))
     return out
 
 
