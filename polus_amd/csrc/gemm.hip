@@ -51,25 +51,42 @@ struct GemmArgs {
 
 template <typename T> union Chunk { uint4 u; T e[16 / sizeof(T)]; };
 
-// ---- HBM -> registers: one operand tile = 1024 16-byte chunks, 4 per thread
-template <typename T>
+// ---- HBM -> registers: one operand tile = 1024 16-byte chunks, 4 per thread.
+// Branch-free on purpose: a per-lane `if` around a global load makes hipcc wait vmcnt(0)
+// at every join, which serialises the eight loads of a K-step.  Invalid chunks read a clamped
+// (in-bounds) address and are zeroed by a select.  VEC = every 16-byte chunk is wholly valid
+// or wholly invalid and 16-byte aligned (checked on the host); otherwise the element path
+// loads each element with its own predicate (tiny heads only).
+// 16 zero bytes in HBM: invalid chunks load from here, so no select has to consume the loaded
+// value (a select right after the load would pull its s_waitcnt in front of the MFMAs).
+__device__ const uint4 g_zero_chunk[1] = {{0u, 0u, 0u, 0u}};
+
+template <typename T, bool VEC>
+__device__ __forceinline__ uint4 load_chunk(const T* __restrict__ base, long off, bool ok, int nvalid) {
+    constexpr int EPC = Cfg<T>::EPC;
+    const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+    Chunk<T> v;
+    if (VEC) {
+        const T* p = ok ? base + off : zero;
+        v.u = *reinterpret_cast<const uint4*>(p);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const T* p = (ok && e < nvalid) ? base + off + e : zero;
+            v.e[e] = *p;
+        }
+    }
+    return v.u;
+}
+template <typename T, bool VEC>
 __device__ __forceinline__ void gload_kc(uint4 (&r)[4], const T* __restrict__ base, long ld, int rows,
-                                         int r0, int k0, int kend, int vec, int tid) {
+                                         int r0, int k0, int kend, int tid) {
     constexpr int EPC = Cfg<T>::EPC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int c = tid + NTHREADS * i;
         int gr = r0 + (c >> 3), gk = k0 + (c & 7) * EPC;
-        Chunk<T> v; v.u = make_uint4(0, 0, 0, 0);
-        if (gr < rows && gk < kend) {
-            const T* p = base + (long)gr * ld + gk;
-            if (vec && gk + EPC <= kend) v.u = *reinterpret_cast<const uint4*>(p);
-            else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) if (gk + e < kend) v.e[e] = p[e];
-            }
-        }
-        r[i] = v.u;
+        r[i] = load_chunk<T, VEC>(base, (long)gr * ld + gk, gr < rows && gk < kend, kend - gk);
     }
 }
 template <typename T>
@@ -80,24 +97,15 @@ __device__ __forceinline__ void sstore_kc(unsigned char* tile, const uint4 (&r)[
         *reinterpret_cast<uint4*>(tile + (c >> 3) * KC_STRIDE + (c & 7) * 16) = r[i];
     }
 }
-template <typename T>
+template <typename T, bool VEC>
 __device__ __forceinline__ void gload_ks(uint4 (&r)[4], const T* __restrict__ base, long ld, int rows,
-                                         int r0, int k0, int kend, int vec, int tid) {
+                                         int r0, int k0, int kend, int tid) {
     constexpr int EPC = Cfg<T>::EPC, LOG = Cfg<T>::LOG_RCH;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int c = tid + NTHREADS * i;
         int gk = k0 + (c >> LOG), gr = r0 + (c & ((1 << LOG) - 1)) * EPC;
-        Chunk<T> v; v.u = make_uint4(0, 0, 0, 0);
-        if (gk < kend && gr < rows) {
-            const T* p = base + (long)gk * ld + gr;
-            if (vec && gr + EPC <= rows) v.u = *reinterpret_cast<const uint4*>(p);
-            else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) if (gr + e < rows) v.e[e] = p[e];
-            }
-        }
-        r[i] = v.u;
+        r[i] = load_chunk<T, VEC>(base, (long)gk * ld + gr, gk < kend && gr < rows, rows - gr);
     }
 }
 template <typename T>
@@ -151,7 +159,7 @@ template <typename TC> __device__ __forceinline__ void st4x(TC* p, const float (
     }
 }
 
-template <typename T, bool A_KS, bool B_KS, typename TC>
+template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = Cfg<T>::BK, NSUB = Cfg<T>::NSUB;
@@ -182,10 +190,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
 
     uint4 ra[4], rb[4];
     auto gload = [&](int k0) {
-        if (A_KS) gload_ks<T>(ra, A, p.lda, p.M, m0, k0, kend, p.a_vec, tid);
-        else      gload_kc<T>(ra, A, p.lda, p.M, m0, k0, kend, p.a_vec, tid);
-        if (B_KS) gload_ks<T>(rb, B, p.ldb, p.N, n0, k0, kend, p.b_vec, tid);
-        else      gload_kc<T>(rb, B, p.ldb, p.N, n0, k0, kend, p.b_vec, tid);
+        if (A_KS) gload_ks<T, VEC>(ra, A, p.lda, p.M, m0, k0, kend, tid);
+        else      gload_kc<T, VEC>(ra, A, p.lda, p.M, m0, k0, kend, tid);
+        if (B_KS) gload_ks<T, VEC>(rb, B, p.ldb, p.N, n0, k0, kend, tid);
+        else      gload_kc<T, VEC>(rb, B, p.ldb, p.N, n0, k0, kend, tid);
     };
     auto sstore = [&](int buf) {
         unsigned char* ta = smem + buf * 2 * OPERAND_BYTES;
@@ -287,10 +295,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     *c = from_f<TC>(s);
 }
 
-template <typename T, bool A_KS, bool B_KS, typename TC>
-int launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
+template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC>
+int launch_v(const GemmArgs& a, dim3 grid, hipStream_t st) {
     static bool attr_done = false;  // per instantiation
-    auto kern = gemm_kernel<T, A_KS, B_KS, TC>;
+    auto kern = gemm_kernel<T, A_KS, B_KS, TC, VEC>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
@@ -299,6 +307,12 @@ int launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), SMEM_BYTES, st, a);
     POLUS_CHECK_LAUNCH("polus_gemm");
     return POLUS_OK;
+}
+
+template <typename T, bool A_KS, bool B_KS, typename TC>
+int launch(const GemmArgs& a, dim3 grid, hipStream_t st) {
+    if (a.a_vec && a.b_vec) return launch_v<T, A_KS, B_KS, TC, true>(a, grid, st);
+    return launch_v<T, A_KS, B_KS, TC, false>(a, grid, st);
 }
 
 template <typename T, typename TC>
@@ -353,8 +367,10 @@ extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
     a.bias = bias; a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = ldaux;
     a.act = act; a.flags = flags;
     a.partial = split_k > 1 ? static_cast<float*>(workspace) : nullptr;
-    a.a_vec = polus_aligned16(A) && ((lda * es) % 16 == 0);
-    a.b_vec = polus_aligned16(B) && ((ldb * es) % 16 == 0);
+    const int epc = (int)(16 / es);
+    // whole-chunk validity: the contiguous extent of each operand must be a multiple of a chunk
+    a.a_vec = polus_aligned16(A) && ((lda * es) % 16 == 0) && ((a_layout == POLUS_K_CONTIG ? K : M) % epc == 0);
+    a.b_vec = polus_aligned16(B) && ((ldb * es) % 16 == 0) && ((b_layout == POLUS_K_CONTIG ? K : N) % epc == 0);
     // 4-wide epilogue accesses: every touched row start must be 4-element aligned
     bool ev = (((uintptr_t)C) % (4 * ecs) == 0) && (ldc % 4 == 0);
     if (bias) ev = ev && (((uintptr_t)bias) % 16 == 0);
