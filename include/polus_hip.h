@@ -171,6 +171,8 @@ int polus_sqnorm(const float* g, int64_t n, float* out, void* workspace, size_t 
 int polus_clip_scale(const float* sqnorm, float grad_scale, float clip_norm, float* out_scale, void* stream);
 /* f32 -> bf16 copy (shadow weights refresh after load / broadcast) and bf16/f32 casts */
 int polus_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+/* dst[cols][rows] = src[rows][cols]^T for bf16 (transposed weight shadow read by dX = dY . W) */
+int polus_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
 /* du = dy * act'(u) elementwise (activation gradient of a Dense whose dY is not produced by
  * a polus_gemm epilogue) */
 int polus_act_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, int act, void* stream);

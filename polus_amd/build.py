@@ -40,7 +40,7 @@ def lib_path():
 
 def build(force=False, verbose=True):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "polus_hip.h")]
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "polus_hip.h")]
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()

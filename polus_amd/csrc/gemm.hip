@@ -16,7 +16,10 @@
 //     ds_read_b32.
 // The MFMA is issued as D[n][m] (B rows as the A operand) so that a lane ends up with four
 // consecutive n of one output row: 8/16-byte epilogue accesses.
-#include "common.h"
+#include <stdlib.h>
+#include "gemm_common.h"
+
+using namespace pgemm;
 
 namespace {
 
@@ -33,20 +36,6 @@ template <> struct Cfg<bf16_t> {
 template <> struct Cfg<float> {
     static constexpr int BK = 32, EPC = 4, NSUB = 1;
     static constexpr int KS_STRIDE = 512, KS_SWZ = 6, LOG_RCH = 5;
-};
-
-struct GemmArgs {
-    const void* A; const void* B; void* C;
-    long lda, ldb, ldc;
-    int M, N, K;
-    int k_per_split;  // multiple of BK
-    float alpha;
-    const float* bias;
-    const void* resid; long ldr;
-    void* aux; long ldaux;
-    int act, flags;
-    float* partial;  // split-K slabs [splits][M][N] or null
-    int a_vec, b_vec, epi_vec;
 };
 
 template <typename T> union Chunk { uint4 u; T e[16 / sizeof(T)]; };
@@ -144,21 +133,6 @@ __device__ __forceinline__ void frag_ks(Frag<float>& f, const unsigned char* til
         f.v[j] = *reinterpret_cast<const float*>(tile + (8 * g + j) * 512 + cb);
 }
 
-template <typename TC> __device__ __forceinline__ void ld4x(const TC* p, float (&v)[4], int vec, int nvalid) {
-    if (vec && nvalid >= 4) load4<TC>(p, v);
-    else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = r < nvalid ? to_f<TC>(p[r]) : 0.0f;
-    }
-}
-template <typename TC> __device__ __forceinline__ void st4x(TC* p, const float (&v)[4], int vec, int nvalid) {
-    if (vec && nvalid >= 4) store4<TC>(p, v);
-    else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r < nvalid) p[r] = from_f<TC>(v[r]);
-    }
-}
-
 template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -167,12 +141,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
     const int i = lane & 15, g = lane >> 4;
     const int wm = wid >> 1, wn = wid & 1;
 
-    // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each
-    // XCD a contiguous run of tiles so neighbours reuse the same A row panel.
     const int tiles_n = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x, nwg = gridDim.x;
-    int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
 
     const int kbeg = blockIdx.z * p.k_per_split;
@@ -228,54 +198,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = tile row i, n = 4g + r
-    const int ev = p.epi_vec;
+    // ---- epilogue
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-        const int m = m0 + wm * 64 + tm * 16 + i;
-        if (m >= p.M) continue;
+    for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int n = n0 + wn * 64 + tn * 16 + 4 * g;
-            const int nvalid = p.N - n;
-            if (nvalid <= 0) continue;
-            float v[4] = {acc[tm][tn][0], acc[tm][tn][1], acc[tm][tn][2], acc[tm][tn][3]};
-            if (p.partial) {
-                float* dst = p.partial + ((long)blockIdx.z * p.M + m) * p.N + n;
-                st4x<float>(dst, v, (p.N & 3) == 0, nvalid);
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-            if (p.bias) {
-                float b[4]; ld4x<float>(p.bias + n, b, ev, nvalid);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b[r];
-            }
-            if (p.flags & POLUS_GEMM_ACT_FWD) {
-                if (p.aux) st4x<T>(static_cast<T*>(p.aux) + (long)m * p.ldaux + n, v, ev, nvalid);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
-            }
-            if (p.flags & POLUS_GEMM_ACT_BWD) {
-                float u[4]; ld4x<T>(static_cast<const T*>(p.aux) + (long)m * p.ldaux + n, u, ev, nvalid);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= apply_act_grad(p.act, u[r]);
-            }
-            if (p.resid) {
-                float rr[4]; ld4x<T>(static_cast<const T*>(p.resid) + (long)m * p.ldr + n, rr, ev, nvalid);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rr[r];
-            }
-            TC* c = static_cast<TC*>(p.C) + (long)m * p.ldc + n;
-            if (p.flags & POLUS_GEMM_ACCUM_C) {
-                float o[4]; ld4x<TC>(c, o, ev, nvalid);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += o[r];
-            }
-            st4x<TC>(c, v, ev, nvalid);
-        }
-    }
+        for (int tn = 0; tn < 4; ++tn)
+            epilogue_tile<T, TC>(p, acc[tm][tn], m0 + wm * 64 + tm * 16 + i, n0 + wn * 64 + tn * 16 + 4 * g, blockIdx.z);
 }
 
 // order-fixed split-K reduction: C = alpha * sum_z slab[z] (+ bias) (+ C)
@@ -382,6 +310,10 @@ extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
+    if (dtype == POLUS_BF16 && a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG && a.a_vec && a.b_vec &&
+        split_k <= 1 && M >= 256 && N >= 192 && !getenv("POLUS_GEMM_V1")) {
+        return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
+    }
     if (dtype == POLUS_BF16) {
         rc = (c_dtype == POLUS_F32) ? dispatch_layout<bf16_t, float>(a_layout, b_layout, a, grid, st)
                                     : dispatch_layout<bf16_t, bf16_t>(a_layout, b_layout, a, grid, st);

@@ -77,6 +77,23 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u
     }
 }
 
+// dst[c][r] = src[r][c] for 2-byte elements, 64x64 tiles through LDS (bf16 weight shadows)
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ src,
+                                                         unsigned short* __restrict__ dst, int R, int C) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? src[(long)r * C + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) dst[(long)c * R + r] = tile[tx][k];
+    }
+}
+
 inline int stream_grid(int64_t n) {
     int64_t b = (n / 4 + 255) / 256;
     if (b < 1) b = 1;
@@ -129,5 +146,14 @@ extern "C" int polus_act_bwd(int dtype, const void* dy, const void* u, void* du,
         hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, st, (const float*)dy, (const float*)u, (float*)du, n, act);
     else POLUS_FAIL("polus_act_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_act_bwd");
+    return POLUS_OK;
+}
+
+extern "C" int polus_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream) {
+    POLUS_REQUIRE(src && dst && rows > 0 && cols > 0, "polus_transpose_bf16: bad arguments");
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const unsigned short*)src, (unsigned short*)dst, rows, cols);
+    POLUS_CHECK_LAUNCH("polus_transpose_bf16");
     return POLUS_OK;
 }

@@ -47,6 +47,16 @@ def dw_split_k(out_rows, out_cols, contraction):
     return int(max(1, min(want, contraction // 256, 64)))
 
 
+def gemm_dx(dy, w, dx, **kw):
+    """dX = dY . W for W stored [out, in]: through the transposed bf16 shadow when the arena
+    keeps one (both operands K-contiguous -> the 256x256 direct-to-LDS kernel), else with W as
+    the K-strided operand."""
+    wt = w.compute_t
+    if wt is not None:
+        return ops.gemm(dy, wt, dx, **kw)
+    return ops.gemm(dy, w.compute, dx, b_layout=ops.K_STRIDED, **kw)
+
+
 def glorot_uniform(rng, fan_in, fan_out, shape):
     lim = math.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)
@@ -151,7 +161,7 @@ class Dense(Layer):
         if not need_dx:
             return None
         dx = self._buf("dx", (rows, self.in_features), x.dtype, x.device)
-        ops.gemm(dy2, self.w.compute, dx, b_layout=ops.K_STRIDED)
+        gemm_dx(dy2, self.w, dx)
         return dx
 
 

@@ -272,3 +272,11 @@ def act_bwd(dy, u, du, act):
     assert dy.numel() == u.numel() == du.numel() and dy.is_contiguous() and u.is_contiguous() and du.is_contiguous()
     check(_lib.load().polus_act_bwd(dtype_code(dy.dtype), ptr(dy), ptr(u), ptr(du), dy.numel(),
                                     ACT_CODES[act] if not isinstance(act, int) else act, _st()), "polus_act_bwd")
+
+
+def transpose_bf16(src, dst):
+    _req_cuda(src, dst)
+    R, C = src.shape
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and dst.numel() == src.numel()
+    assert src.is_contiguous() and dst.is_contiguous()
+    check(_lib.load().polus_transpose_bf16(ptr(src), ptr(dst), R, C, _st()), "polus_transpose_bf16")

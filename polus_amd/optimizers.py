@@ -140,6 +140,7 @@ class Adam:
             ops.adam_step(arena.params, arena.grads, m, v, arena.shadow, seg, n_seg, lr, lr_t,
                           self.beta_1, self.beta_2, self.epsilon, self.weight_decay_rate,
                           grad_scale=self.grad_scale, clip_scale=clip)
+            arena.refresh_transposed()
 
 
 class AdamWeightDecay(Adam):

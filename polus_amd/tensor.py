@@ -85,6 +85,13 @@ class Variable:
         return self._view(self.arena.grads)
 
     @property
+    def compute_t(self):
+        """bf16 transposed shadow [in, out] (K-contiguous B operand of dX = dY . W), or None."""
+        if self.arena.shadow_t is not None and self.matrix and len(self.shape) == 2:
+            return self.arena.shadow_t[self.offset:self.offset + self.size].view(self.shape[1], self.shape[0])
+        return None
+
+    @property
     def compute(self):
         """The tensor GEMMs read: the bf16 shadow in bf16 mode, the f32 master otherwise."""
         if self.arena.shadow is not None and self.matrix:
@@ -113,7 +120,7 @@ class ParamArena:
         self.device = dev or device()
         self.compute_dtype = compute_dtype
         self.vars = []
-        self.params = self.grads = self.shadow = None
+        self.params = self.grads = self.shadow = self.shadow_t = None
         self.size = 0
 
     def add(self, name, shape, init, decay=True, matrix=False):
@@ -137,7 +144,19 @@ class ParamArena:
         if self.compute_dtype == torch.bfloat16:
             self.shadow = torch.empty(self.size, dtype=torch.bfloat16, device=self.device)
             ops.cast(self.params, self.shadow)
+            self.shadow_t = torch.empty(self.size, dtype=torch.bfloat16, device=self.device)
+            self.refresh_transposed()
         return self
+
+    def refresh_transposed(self, var=None):
+        """Re-derive the transposed bf16 shadows from the bf16 shadows (after every optimizer
+        step / load / broadcast): 2 x 2 bytes per GEMM weight of extra HBM traffic."""
+        if self.shadow_t is None:
+            return
+        from . import ops
+        for v in ([var] if var is not None else self.vars):
+            if v.matrix and len(v.shape) == 2:
+                ops.transpose_bf16(v.compute, v.compute_t)
 
     def refresh_shadow(self, var=None):
         if self.shadow is None:
@@ -145,9 +164,12 @@ class ParamArena:
         from . import ops
         if var is None:
             ops.cast(self.params, self.shadow)
+            self.refresh_transposed()
+            return
         else:
             n = (var.size + 3) // 4 * 4
             ops.cast(self.params[var.offset:var.offset + n], self.shadow[var.offset:var.offset + n])
+        self.refresh_transposed(var)
 
     def zero_grads(self):
         self.grads.zero_()

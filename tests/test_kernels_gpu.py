@@ -405,3 +405,70 @@ def test_sqnorm_clip_cast_scale(ops):
     assert torch.equal(b, g_t.to(torch.bfloat16))
     ops.scale_(g_t, 0.25)
     assert_close(host(g_t), g * 0.25, 1e-7, "scale")
+
+
+# ------------------------------------------------------------------------------- 256x256 direct-to-LDS GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 768), (300, 200, 72), (1000, 520, 264),
+                                   (257, 193, 8), (2048, 3072, 768), (1024, 768, 3072)])
+def test_gemm256_matches_reference_and_v1(ops, M, N, K, monkeypatch):
+    r = rng(M + N + K)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K))
+    a_t, b_t = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    ref = rounded(A, torch.bfloat16) @ rounded(B, torch.bfloat16).T
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(a_t, b_t, out)
+    assert_close(host(out), ref, TOL[torch.bfloat16], f"gemm256 {M}x{N}x{K}")
+    o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm(a_t, b_t, o32)
+    assert_close(host(o32), ref, 2e-5 * max(1, K / 64), "gemm256 f32 out")
+    monkeypatch.setenv("POLUS_GEMM_V1", "1")
+    o1 = torch.empty_like(o32)
+    ops.gemm(a_t, b_t, o1)
+    monkeypatch.delenv("POLUS_GEMM_V1")
+    assert_close(host(o32), host(o1), 1e-5, "gemm256 vs 128x128 kernel")
+    # run-to-run bitwise identical (no atomics, fixed k order)
+    o2 = torch.empty_like(o32)
+    ops.gemm(a_t, b_t, o2)
+    assert torch.equal(o32, o2)
+
+
+def test_gemm256_epilogues_and_identity(ops):
+    M, N, K = 384, 256, 192
+    r = rng(77)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.2
+    bias, R = r.standard_normal(N), r.standard_normal((M, N))
+    dt = torch.bfloat16
+    a_t, b_t, bias_t, r_t = dev(A, dt), dev(B, dt), dev(bias, torch.float32), dev(R, dt)
+    base = rounded(A, dt) @ rounded(B, dt).T
+    out = torch.empty((M, N), dtype=dt, device="cuda")
+    aux = torch.empty((M, N), dtype=dt, device="cuda")
+    ops.gemm(a_t, b_t, out, bias=bias_t, resid=r_t)
+    assert_close(host(out), base + bias + rounded(R, dt), TOL[dt], "bias+resid")
+    ops.gemm(a_t, b_t, out, bias=bias_t, aux=aux, act="gelu", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(aux), base + bias, TOL[dt], "aux")
+    assert_close(host(out), ob.gelu(base + bias), TOL[dt], "gelu")
+    ops.gemm(a_t, b_t, out, aux=aux, act="gelu", flags=ops.GEMM_ACT_BWD, resid=r_t)
+    assert_close(host(out), base * ob.gelu_grad(host(aux)) + rounded(R, dt), TOL[dt], "act bwd + resid")
+    # A = I with an asymmetric B: catches any row/col or swizzle mix-up exactly
+    n = 256
+    Bm = (np.arange(n)[:, None] * 3 + np.arange(n)[None, :] % 7).astype(np.float64) / 64.0
+    o = torch.zeros((n, n), dtype=dt, device="cuda")
+    ops.gemm(dev(np.eye(n), dt), dev(Bm, dt), o)
+    assert np.array_equal(host(o), rounded(Bm, dt).T)
+
+
+def test_transposed_shadow_dx(ops):
+    from polus_amd.layers import gemm_dx
+    from polus_amd.tensor import ParamArena
+    arena = ParamArena(torch.bfloat16)
+    r = rng(31)
+    W = r.standard_normal((320, 256)) * 0.1
+    w = arena.add("w", (320, 256), W.astype(np.float32), matrix=True)
+    arena.finalize()
+    assert torch.equal(w.compute_t, w.compute.t().contiguous())
+    dY = r.standard_normal((512, 320))
+    dx = torch.empty((512, 256), dtype=torch.bfloat16, device="cuda")
+    gemm_dx(dev(dY, torch.bfloat16), w, dx)
+    assert_close(host(dx), rounded(dY, torch.bfloat16) @ rounded(W.astype(np.float32), torch.bfloat16), TOL[torch.bfloat16], "dx via W^T shadow")
+    w.assign(W.astype(np.float32) * 2)
+    assert torch.equal(w.compute_t, w.compute.t().contiguous())
