@@ -54,9 +54,22 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 }
 
 // ---------------------------------------------------------------- activations
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf: Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, one v_rcp + one v_exp + 6 FMAs) instead of
+// the ~60-instruction libm erff: the GELU epilogue of FFN1 touches 50 M elements per layer.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float r = 1.0f - poly * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
     float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
@@ -65,17 +78,38 @@ __device__ __forceinline__ float swish_grad_f(float x) {
     float s = 1.0f / (1.0f + __expf(-x));
     return s * (1.0f + x * (1.0f - s));
 }
-__device__ __forceinline__ float apply_act(int act, float x) {
-    return act == POLUS_ACT_GELU ? gelu_f(x) : act == POLUS_ACT_SWISH ? swish_f(x)
-         : act == POLUS_ACT_RELU ? fmaxf(x, 0.0f) : act == POLUS_ACT_TANH ? tanhf(x) : x;
+// `act` is wave-uniform (a kernel argument): real branches, so only one activation is evaluated
+// (nested selects would compute erf, exp and tanh for every element).
+template <int N> __device__ __forceinline__ void apply_act_n(int act, float (&v)[N]) {
+    if (act == POLUS_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = gelu_f(v[r]);
+    } else if (act == POLUS_ACT_SWISH) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = swish_f(v[r]);
+    } else if (act == POLUS_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = fmaxf(v[r], 0.0f);
+    } else if (act == POLUS_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = tanhf(v[r]);
+    }
 }
-// derivative given the pre-activation u
-__device__ __forceinline__ float apply_act_grad(int act, float u) {
-    if (act == POLUS_ACT_GELU) return gelu_grad_f(u);
-    if (act == POLUS_ACT_SWISH) return swish_grad_f(u);
-    if (act == POLUS_ACT_RELU) return u > 0.0f ? 1.0f : 0.0f;
-    if (act == POLUS_ACT_TANH) { float t = tanhf(u); return 1.0f - t * t; }
-    return 1.0f;
+// v[r] *= act'(u[r]) given the pre-activations u
+template <int N> __device__ __forceinline__ void apply_act_grad_n(int act, float (&v)[N], const float (&u)[N]) {
+    if (act == POLUS_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] *= gelu_grad_f(u[r]);
+    } else if (act == POLUS_ACT_SWISH) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] *= swish_grad_f(u[r]);
+    } else if (act == POLUS_ACT_RELU) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = u[r] > 0.0f ? v[r] : 0.0f;
+    } else if (act == POLUS_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) { float t = tanhf(u[r]); v[r] *= 1.0f - t * t; }
+    }
 }
 
 // ---------------------------------------------------------------- wave64 reductions

@@ -59,13 +59,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4& ac
     }
     if (p.flags & POLUS_GEMM_ACT_FWD) {
         if (p.aux) st4x<T>(static_cast<T*>(p.aux) + (long)m * p.ldaux + n, v, ev, nvalid);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(p.act, v[r]);
+        apply_act_n<4>(p.act, v);
     }
     if (p.flags & POLUS_GEMM_ACT_BWD) {
         float u[4]; ld4x<T>(static_cast<const T*>(p.aux) + (long)m * p.ldaux + n, u, ev, nvalid);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= apply_act_grad(p.act, u[r]);
+        apply_act_grad_n<4>(p.act, v, u);
     }
     if (p.resid) {
         float rr[4]; ld4x<T>(static_cast<const T*>(p.resid) + (long)m * p.ldr + n, rr, ev, nvalid);

@@ -68,11 +68,10 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u
             float a[4], b[4];
             load4<T>(dy + i4, a);
             load4<T>(u + i4, b);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] *= apply_act_grad(act, b[e]);
+            apply_act_grad_n<4>(act, a, b);
             store4<T>(du + i4, a);
         } else {
-            for (int64_t j = i4; j < n; ++j) du[j] = from_f<T>(to_f<T>(dy[j]) * apply_act_grad(act, to_f<T>(u[j])));
+            for (int64_t j = i4; j < n; ++j) { float a1[1] = {to_f<T>(dy[j])}, b1[1] = {to_f<T>(u[j])}; apply_act_grad_n<1>(act, a1, b1); du[j] = from_f<T>(a1[0]); }
         }
     }
 }
