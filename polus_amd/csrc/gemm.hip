@@ -305,14 +305,22 @@ extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
     if (resid) ev = ev && (((uintptr_t)resid) % (4 * es) == 0) && (ldr % 4 == 0);
     if (aux) ev = ev && (((uintptr_t)aux) % (4 * es) == 0) && (ldaux % 4 == 0);
     a.epi_vec = ev;
+    bool ev16 = (((uintptr_t)C) % 16 == 0) && ((ldc * ecs) % 16 == 0);
+    if (bias) ev16 = ev16 && (((uintptr_t)bias) % 16 == 0);
+    if (resid) ev16 = ev16 && (((uintptr_t)resid) % 16 == 0) && ((ldr * es) % 16 == 0);
+    if (aux) ev16 = ev16 && (((uintptr_t)aux) % 16 == 0) && ((ldaux * es) % 16 == 0);
+    a.epi_vec16 = ev16 && dtype == POLUS_BF16;
+    { const char* ab = getenv("POLUS_GEMM_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc;
     if (dtype == POLUS_BF16 && a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG && a.a_vec && a.b_vec &&
-        split_k <= 1 && M >= 256 && N >= 192 && !getenv("POLUS_GEMM_V1")) {
-        return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
+        split_k <= 1 && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
+        // POLUS_GEMM_256=1 selects the one-workgroup-per-CU 256x256 kernel (kept for A/B runs)
+        if (getenv("POLUS_GEMM_256") && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
+        return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, st);
     }
     if (dtype == POLUS_BF16) {
         rc = (c_dtype == POLUS_F32) ? dispatch_layout<bf16_t, float>(a_layout, b_layout, a, grid, st)

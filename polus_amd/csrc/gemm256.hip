@@ -123,7 +123,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
     for (int t = 0; t < nk; ++t) {
         const unsigned char* st = smem + (t & 1) * STAGE;
         const int nst = (t + 1) & 1, nk0 = (t + 1) * TK;
-        const bool more = (t + 1 < nk);
+        const bool more = (t + 1 < nk) && !(p.ablate & 1);
+        const bool nomma = p.ablate & 2;
         Frag<bf16_t> af[4][2], bfr[2][2];
 
         // ---- phase 1: quadrant (m 0..3, n 0..1)
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
         for (int nt = 0; nt < 2; ++nt) ldb_frag(bfr[nt], st, nt);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) lda_frag(af[mt], st, mt);
+        if (!nomma) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
                 mma16(acc[mt][nt], bfr[nt][1], af[mt][1]);
             }
         __builtin_amdgcn_s_setprio(0);
+        } else { asm volatile("" :: "v"(af[0][0].v), "v"(af[1][0].v), "v"(af[2][0].v), "v"(af[3][0].v), "v"(af[0][1].v), "v"(af[1][1].v), "v"(af[2][1].v), "v"(af[3][1].v), "v"(bfr[0][0].v), "v"(bfr[1][0].v), "v"(bfr[0][1].v), "v"(bfr[1][1].v)); }
         if (more) POLUS_VMCNT(4); else POLUS_VMCNT(2);   // retires G2(t) = B hi
         __builtin_amdgcn_s_barrier();
 
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
         if (more) issue_b_lo(nst, nk0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) ldb_frag(bfr[nt], st, 2 + nt);
+        if (!nomma) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
                 mma16(acc[mt][2 + nt], bfr[nt][1], af[mt][1]);
             }
         __builtin_amdgcn_s_setprio(0);
+        } else { asm volatile("" :: "v"(af[0][0].v), "v"(af[1][0].v), "v"(af[2][0].v), "v"(af[3][0].v), "v"(af[0][1].v), "v"(af[1][1].v), "v"(af[2][1].v), "v"(af[3][1].v), "v"(bfr[0][0].v), "v"(bfr[1][0].v), "v"(bfr[0][1].v), "v"(bfr[1][1].v)); }
         if (more) POLUS_VMCNT(4); else POLUS_VMCNT(0);   // retires G3(t) = A hi
         __builtin_amdgcn_s_barrier();
 
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
         if (more) issue_b_hi(nst, nk0);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) lda_frag(af[mt], st, 4 + mt);
+        if (!nomma) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -173,11 +179,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
                 mma16(acc[4 + mt][2 + nt], bfr[nt][1], af[mt][1]);
             }
         __builtin_amdgcn_s_setprio(0);
+        } else { asm volatile("" :: "v"(af[0][0].v), "v"(af[1][0].v), "v"(af[2][0].v), "v"(af[3][0].v), "v"(af[0][1].v), "v"(af[1][1].v), "v"(af[2][1].v), "v"(af[3][1].v), "v"(bfr[0][0].v), "v"(bfr[1][0].v), "v"(bfr[0][1].v), "v"(bfr[1][1].v)); }
 
         // ---- phase 4: quadrant (m 4..7, n 0..1)
         if (more) issue_a_hi(nst, nk0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) ldb_frag(bfr[nt], st, nt);
+        if (!nomma) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -187,18 +195,19 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
                 mma16(acc[4 + mt][nt], bfr[nt][1], af[mt][1]);
             }
         __builtin_amdgcn_s_setprio(0);
+        } else { asm volatile("" :: "v"(af[0][0].v), "v"(af[1][0].v), "v"(af[2][0].v), "v"(af[3][0].v), "v"(af[0][1].v), "v"(af[1][1].v), "v"(af[2][1].v), "v"(af[3][1].v), "v"(bfr[0][0].v), "v"(bfr[1][0].v), "v"(bfr[0][1].v), "v"(bfr[1][1].v)); }
         if (more) {
             POLUS_VMCNT(4);                              // retires G1(t+1) = A lo, B lo
             __builtin_amdgcn_s_barrier();
+        } else if (t + 1 < nk) {
+            __builtin_amdgcn_s_barrier();                // ablation build only
         }
     }
 
-    // ---- epilogue
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-            epilogue_tile<bf16_t, TC>(p, acc[mt][nt], m0 + wm * 128 + mt * 16 + i, n0 + wn * 64 + nt * 16 + 4 * g, 0);
+    // every wave is done with the operand stages (and no DMA is in flight): reuse LDS for the C staging
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
 template <typename TC>

@@ -17,6 +17,8 @@ struct GemmArgs {
     int act, flags;
     float* partial;  // split-K slabs [splits][M][N] or null
     int a_vec, b_vec, epi_vec;
+    int epi_vec16;   // C / resid / aux / bias rows allow 16-byte accesses at 8-column granularity
+    int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
 };
 
 template <typename TC> __device__ __forceinline__ void ld4x(const TC* p, float (&v)[4], int vec, int nvalid) {
@@ -79,6 +81,117 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4& ac
     st4x<TC>(c, v, ev, nvalid);
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// Same epilogue, staged through LDS so that HBM sees whole 128-byte lines: the accumulator
+// layout (lane = one row, 4 columns; a store instruction touches 16 rows x 32 B) is turned into
+// row-major (8 lanes = one 128-byte row segment of 64 columns, 16 B per lane) through a
+// wave-private 32-row x 64-column f32 buffer (272-byte rows: conflict-free b128 writes).  LDS
+// operations of one wave execute in order, so no barrier is involved.  `lds` must point to
+// 8704 bytes owned by this wave; the caller guarantees nobody still reads operand tiles there.
+template <typename TC>
+__device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x4 (&acc)[8][4], int mb, int nb,
+                                                         int lane, unsigned char* lds) {
+    typedef bf16_t T;
+    const int i = lane & 15, g = lane >> 4;
+    const bool interior = p.epi_vec16 && !p.partial && (mb + 128 <= p.M) && (nb + 64 <= p.N);
+    if (!interior) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                epilogue_tile<T, TC>(p, acc[mt][nt], mb + mt * 16 + i, nb + nt * 16 + 4 * g, 0);
+        return;
+    }
+    constexpr int RS = 272;
+    const int rrow = lane >> 3, cg = lane & 7;
+    const int ncol = nb + 8 * cg;
+    float bv[8];
+    if (p.bias) { load4<float>(p.bias + ncol, *reinterpret_cast<float(*)[4]>(&bv[0])); load4<float>(p.bias + ncol + 4, *reinterpret_cast<float(*)[4]>(&bv[4])); }
+    else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bv[r] = 0.f;
+    }
+    const bool act_fwd = p.flags & POLUS_GEMM_ACT_FWD, act_bwd = p.flags & POLUS_GEMM_ACT_BWD;
+    const bool accum = p.flags & POLUS_GEMM_ACCUM_C;
+    const T* resid = static_cast<const T*>(p.resid);
+    T* aux = static_cast<T*>(p.aux);
+    TC* C = static_cast<TC*>(p.C);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(lds + (a * 16 + i) * RS + (nt * 16 + 4 * g) * 4) = acc[2 * c + a][nt];
+#pragma unroll
+      for (int ph = 0; ph < 4; ph += 1) {
+        bf16x8_t rr[1], uu[1];
+        float oo[1][8];
+#pragma unroll
+        for (int pq = 0; pq < 1; ++pq) {
+            const int ps = pq;
+            const long m = mb + c * 32 + (ph + pq) * 8 + rrow;
+            if (resid) rr[ps] = *reinterpret_cast<const bf16x8_t*>(resid + m * p.ldr + ncol);
+            if (act_bwd) uu[ps] = *reinterpret_cast<const bf16x8_t*>(aux + m * p.ldaux + ncol);
+            if (accum) {
+                if (sizeof(TC) == 4) {
+                    load4<float>(reinterpret_cast<const float*>(C) + m * p.ldc + ncol, *reinterpret_cast<float(*)[4]>(&oo[ps][0]));
+                    load4<float>(reinterpret_cast<const float*>(C) + m * p.ldc + ncol + 4, *reinterpret_cast<float(*)[4]>(&oo[ps][4]));
+                } else {
+                    bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const T*>(C) + m * p.ldc + ncol);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) oo[ps][r] = (float)t[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int pq = 0; pq < 1; ++pq) {
+            const int ps = pq;
+            const long m = mb + c * 32 + (ph + pq) * 8 + rrow;
+            const unsigned char* src = lds + ((ph + pq) * 8 + rrow) * RS + cg * 32;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bv[r];
+            if (act_fwd) {
+                if (aux) {
+                    bf16x8_t t;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) t[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol) = t;
+                }
+                apply_act_n<8>(p.act, v);
+            }
+            if (act_bwd) {
+                float u[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) u[r] = (float)uu[ps][r];
+                apply_act_grad_n<8>(p.act, v, u);
+            }
+            if (resid) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += (float)rr[ps][r];
+            }
+            if (accum) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += oo[ps][r];
+            }
+            if (sizeof(TC) == 4) {
+                float* dst = reinterpret_cast<float*>(C) + m * p.ldc + ncol;
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                bf16x8_t t;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x8_t*>(reinterpret_cast<T*>(C) + m * p.ldc + ncol) = t;
+            }
+        }
+      }
+    }
+}
+
 // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
 // contiguous run of tiles so that neighbours reuse the same A row panel.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -90,3 +203,5 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // gemm256.hip: bf16, both operands K-contiguous, whole 16-byte chunks.  c_is_f32 selects TC.
 int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st);
+// gemm_ring.hip: same contract, 256x128 tile, two workgroups per CU.
+int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st);

@@ -1,0 +1,156 @@
+// bf16 MFMA GEMM, 256x128 tile, 4 waves, 3-stage LDS-DMA ring, TWO workgroups per CU (gfx950).
+// C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous (forward Dense; dX through the
+// transposed weight shadow).
+//
+// Why two workgroups per CU: with one 8-wave workgroup per CU (gemm256.hip) the per-tile
+// prologue (first loads), epilogue (bias/GELU/residual + C stores, which also have to drain
+// before the next counted wait because vmcnt retires in order) and the LDS-read part of every
+// phase leave the matrix pipe idle, and K = 768 gives only 12 K-steps per tile to amortise them.
+// Two independent 4-wave workgroups (72 KiB LDS, <= 256 VGPRs each) interleave on the 4 SIMDs:
+// one's epilogue / LDS reads / barrier overlap the other's MFMAs.
+//
+// Per workgroup: waves 2(M) x 2(N), 128x64 per wave (8x4 MFMA 16x16x32 tiles), K-step 32 (one
+// MFMA k-step), LDS stage = A 256 rows x 64 B | B 128 rows x 64 B = 24 KiB, ring of 3.  Loads
+// run two K-steps ahead: step t issues tile t+2 (6 x global_load_lds_dwordx4 per wave) into
+// the stage read in step t-1; the only wait is `s_waitcnt vmcnt(6)` + one raw s_barrier per
+// K-step.  LDS-DMA writes are lane-linear (16 rows x 64 B per wave-instruction), so the bank
+// swizzle sits on the source address: LDS chunk pc of row r holds K-chunk pc ^ pi((r>>2)&3),
+// pi = [0,2,3,1]; the fragment read applies the same XOR and every ds_read_b128 lane group hits
+// 16 distinct 16-byte slots.
+#include "gemm_common.h"
+
+using namespace pgemm;
+
+namespace {
+
+constexpr int TM = 256, TN = 128, TK = 32, NTHR = 256;
+constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64;
+constexpr int STAGE = A_BYTES + B_BYTES;   // 24 KiB
+constexpr int NSTAGE = 3;
+constexpr int SMEM_BYTES = NSTAGE * STAGE; // 72 KiB
+
+__device__ const uint4 g_zero_chunk_ring[1] = {{0u, 0u, 0u, 0u}};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+__device__ __forceinline__ int pi4(int q) { return (0x78 >> (2 * q)) & 3; }
+
+#define POLUS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define POLUS_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <typename TC>
+__global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
+    const int K = p.K;
+    const int nk = (K + TK - 1) / TK;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_chunk_ring);
+
+    // ---- per-lane DMA sources: wave w loads A rows 64w..64w+63 (4 pieces) and B rows 32w..32w+31
+    // (2 pieces); lane l of a piece covers row (l>>2), LDS chunk (l&3)
+    const bf16_t* src[6];
+    int kofs[6];       // K offset (elements) of this lane's chunk within a K-step
+    bool rowok[6];
+    int ldsofs[6];     // wave-uniform LDS byte offset of the piece within a stage
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const bool isA = j < 4;
+        const int row = isA ? (64 * wid + 16 * j + (lane >> 2)) : (32 * wid + 16 * (j - 4) + (lane >> 2));
+        const int lc = (lane & 3) ^ pi4((row >> 2) & 3);
+        const int gr = (isA ? m0 : n0) + row;
+        rowok[j] = gr < (isA ? p.M : p.N);
+        kofs[j] = lc * 8;
+        const bf16_t* base = static_cast<const bf16_t*>(isA ? p.A : p.B);
+        src[j] = base + (long)gr * (isA ? p.lda : p.ldb) + lc * 8;
+        ldsofs[j] = isA ? (64 * wid + 16 * j) * 64 : A_BYTES + (32 * wid + 16 * (j - 4)) * 64;
+    }
+    auto issue = [&](int stage, int k0) {
+        unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const bf16_t* s = (rowok[j] && k0 + kofs[j] < K) ? src[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)s, (lds_void_t*)(st + ldsofs[j]), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment address: row R = base16 + i -> (R>>2)&3 = (i>>2)&3; logical chunk g
+    const int fc = (g ^ pi4((i >> 2) & 3)) * 16;
+    const int a_off = (wm * 128 + i) * 64 + fc;             // + mt*1024
+    const int b_off = A_BYTES + (wn * 64 + i) * 64 + fc;    // + nt*1024
+
+    // prologue: two tiles in flight, first one landed
+    issue(0, 0);
+    if (nk > 1) { issue(1, TK); POLUS_VMCNT(6); } else { POLUS_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* st = smem + stage * STAGE;
+        const bool dma = (t + 2 < nk) && !(p.ablate & 1);
+        if (dma) issue(stage == 0 ? 2 : stage - 1, (t + 2) * TK);   // stage read in step t-1
+        Frag<bf16_t> af[8], bfr[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bfr[nt].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) af[mt].v = *reinterpret_cast<const bf16x8*>(st + a_off + mt * 1024);
+        if (p.ablate & 2) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) asm volatile("" :: "v"(af[mt].v));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) asm volatile("" :: "v"(bfr[nt].v));
+        } else {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) mma16(acc[mt][nt], bfr[nt], af[mt]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (t + 1 < nk) {
+            if (dma) POLUS_VMCNT(6); else POLUS_VMCNT(0);   // tile t+1 landed
+            POLUS_LGKMCNT0();
+            __builtin_amdgcn_s_barrier();
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    // every wave is done with the operand stages (and no DMA is in flight): reuse LDS for the C staging
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+}
+
+template <typename TC>
+int launch_ring(const GemmArgs& a, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_ring_kernel<TC>;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        attr_done = true;
+    }
+    const int tiles = ((a.M + TM - 1) / TM) * ((a.N + TN - 1) / TN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), SMEM_BYTES, st, a);
+    POLUS_CHECK_LAUNCH("polus_gemm(ring 256x128)");
+    return POLUS_OK;
+}
+
+}  // namespace
+
+int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, hipStream_t st) {
+    return c_is_f32 ? launch_ring<float>(a, st) : launch_ring<bf16_t>(a, st);
+}

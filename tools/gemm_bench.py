@@ -31,22 +31,24 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--pad", type=int, default=0, help="extra elements in every row stride (breaks power-of-two-ish strides)")
     args = ap.parse_args()
     H, I = (1024, 4096) if args.large else (768, 3072)
     T = args.T
     dt = torch.bfloat16
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).to(dt)
+    P = args.pad
+    rnd = lambda r, c: (torch.rand(r, c + P, device=dev, generator=g) * 2 - 1).to(dt)[:, :c]
     shapes = [("qkv", T, 3 * H, H), ("out", T, H, H), ("ffn1", T, I, H), ("ffn2", T, H, I)]
     rows = []
     for name, M, N, K in shapes:
         if args.only and name not in args.only:
             continue
         a, b = rnd(M, K), rnd(N, K) * 0.05
-        c = torch.empty(M, N, dtype=dt, device=dev)
+        c = torch.empty(M, N + P, dtype=dt, device=dev)[:, :N]
         bias = torch.zeros(N, device=dev)
-        aux = torch.empty(M, N, dtype=dt, device=dev)
+        aux = torch.empty(M, N + P, dtype=dt, device=dev)[:, :N]
         res = rnd(M, N)
         fl = 2.0 * M * N * K
         variants = {
@@ -56,21 +58,24 @@ def main():
             "bias+resid": lambda: ops.gemm(a, b, c, bias=bias, resid=res),
         }
         for vname, fn in variants.items():
+            t3 = bench(fn, args.iters)
+            os.environ["POLUS_GEMM_256"] = "1"
             t2 = bench(fn, args.iters)
+            del os.environ["POLUS_GEMM_256"]
             os.environ["POLUS_GEMM_V1"] = "1"
             t1 = bench(fn, args.iters)
             del os.environ["POLUS_GEMM_V1"]
-            rows.append((name, M, N, K, vname, fl / t2 / 1e12, t2 * 1e6, fl / t1 / 1e12, t1 * 1e6))
+            rows.append((name, M, N, K, vname, fl / t3 / 1e12, t3 * 1e6, fl / t2 / 1e12, t2 * 1e6, fl / t1 / 1e12, t1 * 1e6))
         # dW shape: [N, K] = dY^T X, both K-strided, f32 out, split-K as the model uses it
         from polus_amd.layers import dw_split_k
         dy = rnd(M, N)
         gw = torch.empty(N, K, dtype=torch.float32, device=dev)
         sk = dw_split_k(N, K, M)
         t = bench(lambda: ops.gemm(dy, a, gw, a_layout=ops.K_STRIDED, b_layout=ops.K_STRIDED, split_k=sk), args.iters)
-        rows.append((name, N, K, M, f"dW split_k={sk}", 0.0, 0.0, fl / t / 1e12, t * 1e6))
-    print(f"{'gemm':6s} {'M':>6s} {'N':>6s} {'K':>6s} {'epilogue':16s} {'256 TF/s':>9s} {'us':>8s} {'128 TF/s':>9s} {'us':>8s}")
+        rows.append((name, N, K, M, f"dW split_k={sk}", 0.0, 0.0, 0.0, 0.0, fl / t / 1e12, t * 1e6))
+    print(f"{'gemm':6s} {'M':>6s} {'N':>6s} {'K':>6s} {'epilogue':16s} {'ring TF/s':>9s} {'us':>8s} {'256 TF/s':>9s} {'us':>8s} {'128 TF/s':>9s} {'us':>8s}")
     for r in rows:
-        print(f"{r[0]:6s} {r[1]:6d} {r[2]:6d} {r[3]:6d} {r[4]:16s} {r[5]:9.1f} {r[6]:8.1f} {r[7]:9.1f} {r[8]:8.1f}")
+        print(f"{r[0]:6s} {r[1]:6d} {r[2]:6d} {r[3]:6d} {r[4]:16s} {r[5]:9.1f} {r[6]:8.1f} {r[7]:9.1f} {r[8]:8.1f} {r[9]:9.1f} {r[10]:8.1f}")
 
 
 if __name__ == "__main__":
