@@ -18,6 +18,7 @@ struct GemmArgs {
     float* partial;  // split-K slabs [splits][M][N] or null
     int a_vec, b_vec, epi_vec;
     int epi_vec16;   // C / resid / aux / bias rows allow 16-byte accesses at 8-column granularity
+    long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
 };
 
@@ -204,4 +205,5 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // gemm256.hip: bf16, both operands K-contiguous, whole 16-byte chunks.  c_is_f32 selects TC.
 int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st);
 // gemm_ring.hip: same contract, 256x128 tile, two workgroups per CU.
-int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st);
+// k_strided: both operands [K][rows]; splits > 1: blockIdx.y selects [y*k_per_split, ..) and C + y*c_split_stride.
+int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int k_strided, int splits, hipStream_t st);

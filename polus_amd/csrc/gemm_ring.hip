@@ -17,6 +17,13 @@
 // swizzle sits on the source address: LDS chunk pc of row r holds K-chunk pc ^ pi((r>>2)&3),
 // pi = [0,2,3,1]; the fragment read applies the same XOR and every ds_read_b128 lane group hits
 // 16 distinct 16-byte slots.
+//
+// KS = true is the dW = dY^T X form: both operands K-strided ([K][rows] in memory).  Their LDS
+// images stay k-major (A: 32 k-rows x 512 B, B: 32 k-rows x 256 B; a DMA piece = 2 resp. 4 whole
+// k-rows, full 128-byte lines from HBM), fragments come out of ds_read_b64_tr_b16, and the
+// 32-byte unit index inside a k-row is XORed with (k&3) | ((k>>3)&1)<<2 on the DMA source side
+// and on the read side, so the 8 k-rows a half-wave reads fall on 8 distinct 32-byte bank
+// windows.  Split-K over blockIdx.y writes f32 slabs reduced by an order-fixed second kernel.
 #include "gemm_common.h"
 
 using namespace pgemm;
@@ -39,7 +46,7 @@ __device__ __forceinline__ int pi4(int q) { return (0x78 >> (2 * q)) & 3; }
 #define POLUS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define POLUS_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <typename TC>
+template <typename TC, bool KS>
 __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -50,34 +57,50 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     const int tiles_n = (p.N + TN - 1) / TN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
-    const int K = p.K;
-    const int nk = (K + TK - 1) / TK;
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int K = min(p.K, kbeg + p.k_per_split);   // this split's k range is [kbeg, K)
+    const int nk = (K - kbeg + TK - 1) / TK;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_chunk_ring);
 
     // ---- per-lane DMA sources: wave w loads A rows 64w..64w+63 (4 pieces) and B rows 32w..32w+31
     // (2 pieces); lane l of a piece covers row (l>>2), LDS chunk (l&3)
     const bf16_t* src[6];
-    int kofs[6];       // K offset (elements) of this lane's chunk within a K-step
+    int kofs[6];       // K offset of this lane's chunk within a K-step (elements for KC, k-rows for KS)
     bool rowok[6];
     int ldsofs[6];     // wave-uniform LDS byte offset of the piece within a stage
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const bool isA = j < 4;
-        const int row = isA ? (64 * wid + 16 * j + (lane >> 2)) : (32 * wid + 16 * (j - 4) + (lane >> 2));
-        const int lc = (lane & 3) ^ pi4((row >> 2) & 3);
-        const int gr = (isA ? m0 : n0) + row;
-        rowok[j] = gr < (isA ? p.M : p.N);
-        kofs[j] = lc * 8;
         const bf16_t* base = static_cast<const bf16_t*>(isA ? p.A : p.B);
-        src[j] = base + (long)gr * (isA ? p.lda : p.ldb) + lc * 8;
-        ldsofs[j] = isA ? (64 * wid + 16 * j) * 64 : A_BYTES + (32 * wid + 16 * (j - 4)) * 64;
+        const long ld = isA ? p.lda : p.ldb;
+        if (!KS) {
+            const int row = isA ? (64 * wid + 16 * j + (lane >> 2)) : (32 * wid + 16 * (j - 4) + (lane >> 2));
+            const int lc = (lane & 3) ^ pi4((row >> 2) & 3);
+            const int gr = (isA ? m0 : n0) + row;
+            rowok[j] = gr < (isA ? p.M : p.N);
+            kofs[j] = lc * 8;
+            src[j] = base + (long)gr * ld + lc * 8;
+            ldsofs[j] = isA ? (64 * wid + 16 * j) * 64 : A_BYTES + (32 * wid + 16 * (j - 4)) * 64;
+        } else {
+            // A: piece = 2 k-rows x 512 B, wave w owns k-rows 8w..8w+7; B: piece = 4 k-rows x 256 B
+            const int krow = isA ? (8 * wid + 2 * j + (lane >> 5)) : (8 * wid + 4 * (j - 4) + (lane >> 4));
+            const int pc = isA ? (lane & 31) : (lane & 15);
+            const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+            const int lc = pc ^ (f << 1);
+            const int gr = (isA ? m0 : n0) + lc * 8;
+            rowok[j] = gr < (isA ? p.M : p.N);
+            kofs[j] = krow;
+            src[j] = base + (long)krow * ld + gr;
+            ldsofs[j] = isA ? (8 * wid + 2 * j) * 512 : A_BYTES + (8 * wid + 4 * (j - 4)) * 256;
+        }
     }
+    const long a_kstep = KS ? (long)p.lda : 1, b_kstep = KS ? (long)p.ldb : 1;
     auto issue = [&](int stage, int k0) {
         unsigned char* st = smem + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const bf16_t* s = (rowok[j] && k0 + kofs[j] < K) ? src[j] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)s, (lds_void_t*)(st + ldsofs[j]), 16, 0, 0);
+            const bf16_t* sp = (rowok[j] && k0 + kofs[j] < K) ? src[j] + (long)k0 * (j < 4 ? a_kstep : b_kstep) : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (lds_void_t*)(st + ldsofs[j]), 16, 0, 0);
         }
     };
 
@@ -89,24 +112,57 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
 
     // fragment address: row R = base16 + i -> (R>>2)&3 = (i>>2)&3; logical chunk g
     const int fc = (g ^ pi4((i >> 2) & 3)) * 16;
-    const int a_off = (wm * 128 + i) * 64 + fc;             // + mt*1024
-    const int b_off = A_BYTES + (wn * 64 + i) * 64 + fc;    // + nt*1024
+    int a_off, b_off;
+    if (!KS) {
+        a_off = (wm * 128 + i) * 64 + fc;             // + mt*1024
+        b_off = A_BYTES + (wn * 64 + i) * 64 + fc;    // + nt*1024
+    } else {
+        // transposed read: lane (i,g) passes k-row 8g + (i>>2) (+4 for the second half), columns 4*(i&3)..+3
+        const int krow = 8 * g + (i >> 2);
+        const int fx = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 5;    // same for krow + 4
+        a_off = krow * 512 + (((wm * 128) * 2 + (i & 3) * 8) ^ fx);    // + (mt*32 ^ ...) handled below
+        b_off = A_BYTES + krow * 256 + (((wn * 64) * 2 + (i & 3) * 8) ^ fx);
+    }
 
     // prologue: two tiles in flight, first one landed
-    issue(0, 0);
-    if (nk > 1) { issue(1, TK); POLUS_VMCNT(6); } else { POLUS_VMCNT(0); }
+    issue(0, kbeg);
+    if (nk > 1) { issue(1, kbeg + TK); POLUS_VMCNT(6); } else { POLUS_VMCNT(0); }
     __builtin_amdgcn_s_barrier();
 
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
         const unsigned char* st = smem + stage * STAGE;
         const bool dma = (t + 2 < nk) && !(p.ablate & 1);
-        if (dma) issue(stage == 0 ? 2 : stage - 1, (t + 2) * TK);   // stage read in step t-1
+        if (dma) issue(stage == 0 ? 2 : stage - 1, kbeg + (t + 2) * TK);   // stage read in step t-1
         Frag<bf16_t> af[8], bfr[4];
+        if (!KS) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bfr[nt].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 1024);
+            for (int nt = 0; nt < 4; ++nt) bfr[nt].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 1024);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) af[mt].v = *reinterpret_cast<const bf16x8*>(st + a_off + mt * 1024);
+            for (int mt = 0; mt < 8; ++mt) af[mt].v = *reinterpret_cast<const bf16x8*>(st + a_off + mt * 1024);
+        } else {
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            // tile offset t*32 B only touches byte bits >= 5 and the XOR mask is in bits 5..7:
+            // (base ^ fx) + t*32 would be wrong, so the mask is re-applied per tile on bits 5..7
+            const int krow = 8 * g + (i >> 2);
+            const int fx = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 5;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int col = ((wn * 64 + nt * 16) * 2 + (i & 3) * 8) ^ fx;
+                const unsigned char* q = st + A_BYTES + krow * 256 + col;
+                s16x4 lo = lds_tr16(q), hi = lds_tr16(q + 4 * 256);
+                s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[nt].v = __builtin_bit_cast(bf16x8, w);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int col = ((wm * 128 + mt * 16) * 2 + (i & 3) * 8) ^ fx;
+                const unsigned char* q = st + krow * 512 + col;
+                s16x4 lo = lds_tr16(q), hi = lds_tr16(q + 4 * 512);
+                s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[mt].v = __builtin_bit_cast(bf16x8, w);
+            }
+        }
         if (p.ablate & 2) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) asm volatile("" :: "v"(af[mt].v));
@@ -131,26 +187,28 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     // every wave is done with the operand stages (and no DMA is in flight): reuse LDS for the C staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    p.C = static_cast<TC*>(p.C) + (long)blockIdx.y * p.c_split_stride;
     epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
-template <typename TC>
-int launch_ring(const GemmArgs& a, hipStream_t st) {
+template <typename TC, bool KS>
+int launch_ring(const GemmArgs& a, int splits, hipStream_t st) {
     static bool attr_done = false;
-    auto kern = gemm_ring_kernel<TC>;
+    auto kern = gemm_ring_kernel<TC, KS>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         attr_done = true;
     }
     const int tiles = ((a.M + TM - 1) / TM) * ((a.N + TN - 1) / TN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), SMEM_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(NTHR), SMEM_BYTES, st, a);
     POLUS_CHECK_LAUNCH("polus_gemm(ring 256x128)");
     return POLUS_OK;
 }
 
 }  // namespace
 
-int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, hipStream_t st) {
-    return c_is_f32 ? launch_ring<float>(a, st) : launch_ring<bf16_t>(a, st);
+int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int k_strided, int splits, hipStream_t st) {
+    if (k_strided) return c_is_f32 ? launch_ring<float, true>(a, splits, st) : launch_ring<bf16_t, true>(a, splits, st);
+    return c_is_f32 ? launch_ring<float, false>(a, splits, st) : launch_ring<bf16_t, false>(a, splits, st);
 }

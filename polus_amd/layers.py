@@ -40,10 +40,11 @@ class Layer:
 
 
 def dw_split_k(out_rows, out_cols, contraction):
-    """Split-K factor for dW = dY^T X: few output tiles, long contraction. Aim at >= ~2
-    workgroups per CU while keeping >= 256 contraction rows per slice."""
-    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
-    want = max(1, 768 // max(tiles, 1))
+    """Split-K factor for dW = dY^T X: few 256x128 output tiles, long contraction (T).  Aim at
+    one full round of the 512 workgroup slots (2 per CU) while keeping >= 256 contraction rows
+    per slice."""
+    tiles = ((out_rows + 255) // 256) * ((out_cols + 127) // 128)
+    want = max(1, 512 // max(tiles, 1))
     return int(max(1, min(want, contraction // 256, 64)))
 
 

@@ -472,3 +472,31 @@ def test_transposed_shadow_dx(ops):
     assert_close(host(dx), rounded(dY, torch.bfloat16) @ rounded(W.astype(np.float32), torch.bfloat16), TOL[torch.bfloat16], "dx via W^T shadow")
     w.assign(W.astype(np.float32) * 2)
     assert torch.equal(w.compute_t, w.compute.t().contiguous())
+
+
+@pytest.mark.parametrize("T,N,K,splits", [(4096, 768, 768, (1, 4, 7)), (1000, 304, 136, (1, 3)), (2048, 2304, 768, (5,)),
+                                           (8192, 768, 3072, (8,)), (64, 256, 128, (1, 2))])
+def test_gemm_ring_dw_k_strided(ops, T, N, K, splits, monkeypatch):
+    """dW = dY^T X on the ring kernel: k-major LDS images + transposing LDS reads + split-K slabs."""
+    r = rng(T + N + K)
+    dY, X = r.standard_normal((T, N)) * 0.1, r.standard_normal((T, K))
+    dt = torch.bfloat16
+    dy_t, x_t = dev(dY, dt), dev(X, dt)
+    ref = rounded(dY, dt).T @ rounded(X, dt)
+    for sk in splits:
+        out = torch.full((N, K), float("nan"), dtype=torch.float32, device="cuda")
+        ops.gemm(dy_t, x_t, out, a_layout=1, b_layout=1, split_k=sk)
+        assert_close(host(out), ref, 2e-3, f"ring dW split_k={sk}")
+        o2 = torch.empty_like(out)
+        ops.gemm(dy_t, x_t, o2, a_layout=1, b_layout=1, split_k=sk)
+        assert torch.equal(out, o2), "split-K reduction must be bitwise reproducible"
+        monkeypatch.setenv("POLUS_GEMM_V1", "1")
+        o1 = torch.empty_like(out)
+        ops.gemm(dy_t, x_t, o1, a_layout=1, b_layout=1, split_k=sk)
+        monkeypatch.delenv("POLUS_GEMM_V1")
+        assert_close(host(out), host(o1), 2e-5, "ring vs 128x128 kernel")
+    # accumulate + alpha through the split-K reduce kernel
+    base = r.standard_normal((N, K)).astype(np.float32)
+    acc = dev(base)
+    ops.gemm(dy_t, x_t, acc, a_layout=1, b_layout=1, split_k=splits[-1], alpha=0.5, flags=ops.GEMM_ACCUM_C)
+    assert_close(host(acc), 0.5 * ref + base, 2e-3, "ring dW accumulate")
