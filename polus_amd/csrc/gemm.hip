@@ -318,29 +318,21 @@ extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
     int rc = POLUS_OK;
     a.c_split_stride = 0;
     const bool both_kc = a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG;
-    const bool both_ks = a_layout == POLUS_K_STRIDED && b_layout == POLUS_K_STRIDED;
-    if (dtype == POLUS_BF16 && (both_kc || both_ks) && a.a_vec && a.b_vec && M >= 256 && N >= 128 &&
-        !getenv("POLUS_GEMM_V1")) {
-        if (both_kc && split_k <= 1) {
+    const int a_ks = a_layout == POLUS_K_STRIDED, b_ks = b_layout == POLUS_K_STRIDED;
+    if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
+        if (split_k <= 1) {
             // POLUS_GEMM_256=1 selects the one-workgroup-per-CU 256x256 kernel (kept for A/B runs)
-            if (getenv("POLUS_GEMM_256") && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
+            if (both_kc && getenv("POLUS_GEMM_256") && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
             a.k_per_split = ((K + 31) / 32) * 32;
-            return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, 0, 1, st);
+            return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, a_ks, b_ks, 1, st);
         }
-        if (both_ks) {
-            // k_per_split must be a multiple of the ring K-step (32); it already is (multiple of 64)
-            if (split_k <= 1) {
-                a.k_per_split = ((K + 31) / 32) * 32;
-                return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, 1, 1, st);
-            }
-            GemmArgs s = a;              // slabs: plain f32 stores, epilogue applied by the reduce kernel
-            s.C = a.partial; s.ldc = N; s.c_split_stride = (long)M * N; s.partial = nullptr;
-            s.alpha = 1.0f; s.bias = nullptr; s.flags = 0; s.resid = nullptr; s.aux = nullptr;
-            s.epi_vec = (N % 4 == 0); s.epi_vec16 = (N % 4 == 0) && polus_aligned16(a.partial);
-            rc = polus_launch_gemm_ring(s, 1, 1, splits_eff, st);
-            if (rc != POLUS_OK) return rc;
-            goto reduce;
-        }
+        GemmArgs s = a;              // slabs: plain f32 stores, epilogue applied by the reduce kernel
+        s.C = a.partial; s.ldc = N; s.c_split_stride = (long)M * N; s.partial = nullptr;
+        s.alpha = 1.0f; s.bias = nullptr; s.flags = 0; s.resid = nullptr; s.aux = nullptr;
+        s.epi_vec = (N % 4 == 0); s.epi_vec16 = (N % 4 == 0) && polus_aligned16(a.partial);
+        rc = polus_launch_gemm_ring(s, 1, a_ks, b_ks, splits_eff, st);
+        if (rc != POLUS_OK) return rc;
+        goto reduce;
     }
     if (dtype == POLUS_BF16) {
         rc = (c_dtype == POLUS_F32) ? dispatch_layout<bf16_t, float>(a_layout, b_layout, a, grid, st)

@@ -205,5 +205,5 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // gemm256.hip: bf16, both operands K-contiguous, whole 16-byte chunks.  c_is_f32 selects TC.
 int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st);
 // gemm_ring.hip: same contract, 256x128 tile, two workgroups per CU.
-// k_strided: both operands [K][rows]; splits > 1: blockIdx.y selects [y*k_per_split, ..) and C + y*c_split_stride.
-int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int k_strided, int splits, hipStream_t st);
+// a_ks / b_ks: operand stored [K][rows]; splits > 1: blockIdx.y selects [y*k_per_split, ..) and C + y*c_split_stride.
+int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st);

@@ -18,7 +18,8 @@
 // pi = [0,2,3,1]; the fragment read applies the same XOR and every ds_read_b128 lane group hits
 // 16 distinct 16-byte slots.
 //
-// KS = true is the dW = dY^T X form: both operands K-strided ([K][rows] in memory).  Their LDS
+// A_KS / B_KS select K-strided operands ([K][rows] in memory): W in dX = dY W, both dY and X in
+// dW = dY^T X.  Their LDS
 // images stay k-major (A: 32 k-rows x 512 B, B: 32 k-rows x 256 B; a DMA piece = 2 resp. 4 whole
 // k-rows, full 128-byte lines from HBM), fragments come out of ds_read_b64_tr_b16, and the
 // 32-byte unit index inside a k-row is XORed with (k&3) | ((k>>3)&1)<<2 on the DMA source side
@@ -46,7 +47,7 @@ __device__ __forceinline__ int pi4(int q) { return (0x78 >> (2 * q)) & 3; }
 #define POLUS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define POLUS_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <typename TC, bool KS>
+template <typename TC, bool A_KS, bool B_KS>
 __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
         const bool isA = j < 4;
         const bf16_t* base = static_cast<const bf16_t*>(isA ? p.A : p.B);
         const long ld = isA ? p.lda : p.ldb;
-        if (!KS) {
+        const bool ks = isA ? A_KS : B_KS;
+        if (!ks) {
             const int row = isA ? (64 * wid + 16 * j + (lane >> 2)) : (32 * wid + 16 * (j - 4) + (lane >> 2));
             const int lc = (lane & 3) ^ pi4((row >> 2) & 3);
             const int gr = (isA ? m0 : n0) + row;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
             ldsofs[j] = isA ? (8 * wid + 2 * j) * 512 : A_BYTES + (8 * wid + 4 * (j - 4)) * 256;
         }
     }
-    const long a_kstep = KS ? (long)p.lda : 1, b_kstep = KS ? (long)p.ldb : 1;
+    const long a_kstep = A_KS ? (long)p.lda : 1, b_kstep = B_KS ? (long)p.ldb : 1;
     auto issue = [&](int stage, int k0) {
         unsigned char* st = smem + stage * STAGE;
 #pragma unroll
@@ -112,17 +114,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
 
     // fragment address: row R = base16 + i -> (R>>2)&3 = (i>>2)&3; logical chunk g
     const int fc = (g ^ pi4((i >> 2) & 3)) * 16;
-    int a_off, b_off;
-    if (!KS) {
-        a_off = (wm * 128 + i) * 64 + fc;             // + mt*1024
-        b_off = A_BYTES + (wn * 64 + i) * 64 + fc;    // + nt*1024
-    } else {
-        // transposed read: lane (i,g) passes k-row 8g + (i>>2) (+4 for the second half), columns 4*(i&3)..+3
-        const int krow = 8 * g + (i >> 2);
-        const int fx = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 5;    // same for krow + 4
-        a_off = krow * 512 + (((wm * 128) * 2 + (i & 3) * 8) ^ fx);    // + (mt*32 ^ ...) handled below
-        b_off = A_BYTES + krow * 256 + (((wn * 64) * 2 + (i & 3) * 8) ^ fx);
-    }
+    const int a_off = (wm * 128 + i) * 64 + fc;             // K-contiguous image: + mt*1024
+    const int b_off = A_BYTES + (wn * 64 + i) * 64 + fc;    // + nt*1024
+    // K-strided image: lane (i,g) passes k-row 8g + (i>>2) (+4 for the second half), columns 4*(i&3)..+3
+    const int krow = 8 * g + (i >> 2);
+    const int fx = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 5;    // same for krow + 4
 
     // prologue: two tiles in flight, first one landed
     issue(0, kbeg);
@@ -135,17 +131,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
         const bool dma = (t + 2 < nk) && !(p.ablate & 1);
         if (dma) issue(stage == 0 ? 2 : stage - 1, kbeg + (t + 2) * TK);   // stage read in step t-1
         Frag<bf16_t> af[8], bfr[4];
-        if (!KS) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        if (!B_KS) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bfr[nt].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 1024);
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt) af[mt].v = *reinterpret_cast<const bf16x8*>(st + a_off + mt * 1024);
         } else {
-            typedef short s16x8 __attribute__((ext_vector_type(8)));
-            // tile offset t*32 B only touches byte bits >= 5 and the XOR mask is in bits 5..7:
-            // (base ^ fx) + t*32 would be wrong, so the mask is re-applied per tile on bits 5..7
-            const int krow = 8 * g + (i >> 2);
-            const int fx = ((krow & 3) | (((krow >> 3) & 1) << 2)) << 5;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int col = ((wn * 64 + nt * 16) * 2 + (i & 3) * 8) ^ fx;
@@ -154,6 +144,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
                 s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bfr[nt].v = __builtin_bit_cast(bf16x8, w);
             }
+        }
+        if (!A_KS) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) af[mt].v = *reinterpret_cast<const bf16x8*>(st + a_off + mt * 1024);
+        } else {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
                 const int col = ((wm * 128 + mt * 16) * 2 + (i & 3) * 8) ^ fx;
@@ -191,10 +186,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
-template <typename TC, bool KS>
+template <typename TC, bool A_KS, bool B_KS>
 int launch_ring(const GemmArgs& a, int splits, hipStream_t st) {
     static bool attr_done = false;
-    auto kern = gemm_ring_kernel<TC, KS>;
+    auto kern = gemm_ring_kernel<TC, A_KS, B_KS>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
@@ -206,9 +201,16 @@ int launch_ring(const GemmArgs& a, int splits, hipStream_t st) {
     return POLUS_OK;
 }
 
+template <typename TC>
+int launch_layout(const GemmArgs& a, int a_ks, int b_ks, int splits, hipStream_t st) {
+    if (!a_ks && !b_ks) return launch_ring<TC, false, false>(a, splits, st);
+    if (!a_ks && b_ks) return launch_ring<TC, false, true>(a, splits, st);
+    if (a_ks && b_ks) return launch_ring<TC, true, true>(a, splits, st);
+    return launch_ring<TC, true, false>(a, splits, st);
+}
+
 }  // namespace
 
-int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int k_strided, int splits, hipStream_t st) {
-    if (k_strided) return c_is_f32 ? launch_ring<float, true>(a, splits, st) : launch_ring<bf16_t, true>(a, splits, st);
-    return c_is_f32 ? launch_ring<float, false>(a, splits, st) : launch_ring<bf16_t, false>(a, splits, st);
+int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st) {
+    return c_is_f32 ? launch_layout<float>(a, a_ks, b_ks, splits, st) : launch_layout<bf16_t>(a, a_ks, b_ks, splits, st);
 }

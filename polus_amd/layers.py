@@ -49,12 +49,8 @@ def dw_split_k(out_rows, out_cols, contraction):
 
 
 def gemm_dx(dy, w, dx, **kw):
-    """dX = dY . W for W stored [out, in]: through the transposed bf16 shadow when the arena
-    keeps one (both operands K-contiguous -> the 256x256 direct-to-LDS kernel), else with W as
-    the K-strided operand."""
-    wt = w.compute_t
-    if wt is not None:
-        return ops.gemm(dy, wt, dx, **kw)
+    """dX = dY . W for W stored [out, in]: W is the K-strided operand (k-major LDS image read
+    with the transposing LDS read), so no transposed copy of the weights exists."""
     return ops.gemm(dy, w.compute, dx, b_layout=ops.K_STRIDED, **kw)
 
 

@@ -144,8 +144,6 @@ class ParamArena:
         if self.compute_dtype == torch.bfloat16:
             self.shadow = torch.empty(self.size, dtype=torch.bfloat16, device=self.device)
             ops.cast(self.params, self.shadow)
-            self.shadow_t = torch.empty(self.size, dtype=torch.bfloat16, device=self.device)
-            self.refresh_transposed()
         return self
 
     def refresh_transposed(self, var=None):
