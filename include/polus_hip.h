@@ -70,6 +70,16 @@ int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
                int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
                void* stream);
 
+/* ---- Dense backward for the parameters (the dW/db part of tape.gradient, polus/training.py:185):
+ * dW[n_out, n_in] (+)= dY[T, n_out]^T . X[T, n_in]  (f32) and, if db != NULL, db[n_out] (+)= column
+ * sums of dY — one pass over dY (on the bf16 ring kernel the column sums ride on the matrix pipe).
+ * Deterministic split-K over T. */
+size_t polus_dense_bwd_params_workspace_bytes(int T, int n_out, int n_in, int split_k);
+int polus_dense_bwd_params(int dtype, const void* dY, long lddy, const void* X, long ldx,
+                           float* dW, long lddw, float* db, int T, int n_out, int n_in,
+                           int accumulate, int split_k, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ---- fused scaled-dot-product attention (HF TFBertSelfAttention as driven by
  * TFBertSplited.call, polus/models.py:201-216, with the additive key mask
  * (1-m)*-10000 of polus/models.py:175-195).

@@ -25,6 +25,8 @@ SIGNATURES = {
     "polus_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_gemm": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,
                         _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_dense_bwd_params_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "polus_dense_bwd_params": (_i, [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "polus_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "polus_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

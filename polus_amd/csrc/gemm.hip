@@ -317,6 +317,7 @@ extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = POLUS_OK;
     a.c_split_stride = 0;
+    a.colsum_a = nullptr;
     const bool both_kc = a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG;
     const int a_ks = a_layout == POLUS_K_STRIDED, b_ks = b_layout == POLUS_K_STRIDED;
     if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
@@ -355,5 +356,83 @@ reduce:
                                (flags & POLUS_GEMM_ACCUM_C) ? 1 : 0);
         POLUS_CHECK_LAUNCH("polus_gemm(splitk_reduce)");
     }
+    return POLUS_OK;
+}
+
+// ---- Dense backward for the parameters: dW = dY^T X (+)= and db = column sums of dY, one pass
+// over dY.  On the ring kernel the bias gradient rides on the matrix pipe (ones-fragment MFMA).
+extern "C" size_t polus_dense_bwd_params_workspace_bytes(int T, int n_out, int n_in, int split_k) {
+    if (split_k < 1) split_k = 1;
+    size_t slabs = split_k > 1 ? (size_t)split_k * n_out * n_in * sizeof(float) : 0;
+    size_t cs = (size_t)split_k * n_out * sizeof(float);
+    size_t fallback = polus_colsum_workspace_bytes(T, n_out);
+    return slabs + (cs > fallback ? cs : fallback) + 256;
+}
+
+namespace {
+__global__ void colsum_splits_kernel(const float* __restrict__ partial, int splits, int n, float* __restrict__ out, int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(long)z * n + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+}  // namespace
+
+extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, const void* X, long ldx,
+                                      float* dW, long lddw, float* db, int T, int n_out, int n_in,
+                                      int accumulate, int split_k, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    POLUS_REQUIRE(dY && X && dW, "polus_dense_bwd_params: null pointer");
+    POLUS_REQUIRE(T > 0 && n_out > 0 && n_in > 0, "polus_dense_bwd_params: bad shape");
+    if (split_k < 1) split_k = 1;
+    size_t need = polus_dense_bwd_params_workspace_bytes(T, n_out, n_in, split_k);
+    if (!workspace || workspace_bytes < need) { polus_set_error("polus_dense_bwd_params: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t es = polus_dtype_size(dtype);
+    const int bk = dtype == POLUS_BF16 ? 64 : 32;
+    int nkt = (T + bk - 1) / bk;
+    if (split_k > nkt) split_k = nkt;
+    const size_t slab_bytes = split_k > 1 ? (((size_t)split_k * n_out * n_in * sizeof(float) + 255) / 256) * 256 : 0;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    float* cs_ws = reinterpret_cast<float*>(ws + slab_bytes);
+    const bool vec = polus_aligned16(dY) && polus_aligned16(X) && ((lddy * es) % 16 == 0) && ((ldx * es) % 16 == 0) &&
+                     (n_out % (16 / es) == 0) && (n_in % (16 / es) == 0);
+    const bool ring = dtype == POLUS_BF16 && vec && n_out >= 256 && n_in >= 128 && db != nullptr && !getenv("POLUS_GEMM_V1");
+    if (!ring) {
+        int rc = polus_gemm(dtype, POLUS_K_STRIDED, POLUS_K_STRIDED, POLUS_F32, dY, lddy, X, ldx, dW, lddw, n_out, n_in, T,
+                            1.0f, nullptr, nullptr, 0, nullptr, 0, 0, accumulate ? POLUS_GEMM_ACCUM_C : 0, split_k,
+                            ws, slab_bytes, stream);
+        if (rc != POLUS_OK || !db) return rc;
+        return polus_colsum(dtype, dY, lddy, T, n_out, db, accumulate, cs_ws, workspace_bytes - slab_bytes, stream);
+    }
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = dY; a.B = X; a.lda = lddy; a.ldb = ldx;
+    a.M = n_out; a.N = n_in; a.K = T; a.alpha = 1.0f;
+    a.k_per_split = ((nkt + split_k - 1) / split_k) * bk;
+    const int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
+    a.a_vec = a.b_vec = 1;
+    a.colsum_a = cs_ws;
+    { const char* ab = getenv("POLUS_GEMM_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    int rc;
+    if (splits_eff > 1) {
+        a.C = ws; a.ldc = n_in; a.c_split_stride = (long)n_out * n_in;
+        a.epi_vec = (n_in % 4 == 0); a.epi_vec16 = (n_in % 4 == 0);
+        rc = polus_launch_gemm_ring(a, 1, 1, 1, splits_eff, st);
+        if (rc != POLUS_OK) return rc;
+        long total = (long)n_out * n_in;
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)((total + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(ws), splits_eff, n_out, n_in, dW, lddw, 1.0f,
+                           (const float*)nullptr, accumulate ? 1 : 0);
+        POLUS_CHECK_LAUNCH("polus_dense_bwd_params(reduce)");
+    } else {
+        a.C = dW; a.ldc = lddw; a.flags = accumulate ? POLUS_GEMM_ACCUM_C : 0;
+        a.epi_vec = polus_aligned16(dW) && (lddw % 4 == 0); a.epi_vec16 = a.epi_vec;
+        rc = polus_launch_gemm_ring(a, 1, 1, 1, 1, st);
+        if (rc != POLUS_OK) return rc;
+    }
+    hipLaunchKernelGGL(colsum_splits_kernel, dim3((n_out + 255) / 256), dim3(256), 0, st, cs_ws, splits_eff, n_out, db, accumulate ? 1 : 0);
+    POLUS_CHECK_LAUNCH("polus_dense_bwd_params(colsum)");
     return POLUS_OK;
 }

@@ -18,6 +18,7 @@ struct GemmArgs {
     float* partial;  // split-K slabs [splits][M][N] or null
     int a_vec, b_vec, epi_vec;
     int epi_vec16;   // C / resid / aux / bias rows allow 16-byte accesses at 8-column granularity
+    float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
 };

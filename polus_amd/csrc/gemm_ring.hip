@@ -56,8 +56,18 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     const int wm = wid >> 1, wn = wid & 1;
 
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
+    int tile_m, tile_n;
+    if ((p.ablate & 4) && gridDim.x == 512 && (tiles_n & 1) == 0) {
+        // experiment: the two workgroups that share a CU (b, b+256) take n-adjacent tiles (same A rows)
+        const int c = blockIdx.x & 255, h = blockIdx.x >> 8;
+        const int P = xcd_remap(c, 256);
+        tile_m = P / (tiles_n >> 1);
+        tile_n = 2 * (P % (tiles_n >> 1)) + h;
+    } else {
+        const int wg = xcd_remap(blockIdx.x, gridDim.x);
+        tile_m = wg / tiles_n; tile_n = wg % tiles_n;
+    }
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int K = min(p.K, kbeg + p.k_per_split);   // this split's k range is [kbeg, K)
     const int nk = (K - kbeg + TK - 1) / TK;
@@ -111,6 +121,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // column sums of A (dW = dY^T X: sum_t dY[t][m] = bias gradient): D[n][m] = sum_k 1 * A[m][k]
+    const bool want_colsum = A_KS && p.colsum_a != nullptr && wn == 0 && n0 == 0;
+    f32x4 csum[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) csum[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag<bf16_t> ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones.v[e] = (bf16_t)1.0f;
 
     // fragment address: row R = base16 + i -> (R>>2)&3 = (i>>2)&3; logical chunk g
     const int fc = (g ^ pi4((i >> 2) & 3)) * 16;
@@ -169,6 +188,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
             for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) mma16(acc[mt][nt], bfr[nt], af[mt]);
+            if (want_colsum) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) mma16(csum[mt], ones, af[mt]);
+            }
             __builtin_amdgcn_s_setprio(0);
         }
         if (t + 1 < nk) {
@@ -182,6 +205,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     // every wave is done with the operand stages (and no DMA is in flight): reuse LDS for the C staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (want_colsum && g == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wm * 128 + mt * 16 + i;
+            if (m < p.M) p.colsum_a[(long)blockIdx.y * p.M + m] = csum[mt][0];
+        }
+    }
     p.C = static_cast<TC*>(p.C) + (long)blockIdx.y * p.c_split_stride;
     epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }

@@ -24,6 +24,17 @@ __device__ __forceinline__ void load_row(const T* row, int H, int lane, float (&
     }
 }
 
+// per-feature f32 vector (gamma / beta) -> registers, once per wave
+template <int NC>
+__device__ __forceinline__ void load_feat(const float* __restrict__ p, int H, int lane, float (&v)[NC][4]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) load4<float>(p + col, v[c]);
+        else { v[c][0] = v[c][1] = v[c][2] = v[c][3] = 0.f; }
+    }
+}
+
 // mean / rstd of one row held in registers (two-pass, biased variance)
 template <int NC>
 __device__ __forceinline__ void row_stats(const float (&v)[NC][4], int H, int lane, float eps,
@@ -46,17 +57,15 @@ __device__ __forceinline__ void row_stats(const float (&v)[NC][4], int H, int la
 }
 
 template <typename T, int NC>
-__device__ __forceinline__ void normalize_store(const float (&v)[NC][4], const float* gamma, const float* beta,
+__device__ __forceinline__ void normalize_store(const float (&v)[NC][4], const float (&gv)[NC][4], const float (&bv)[NC][4],
                                                 T* y, int H, int lane, float mean, float rstd) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         int col = (lane + 64 * c) * 4;
         if (col < H) {
-            float g[4], b[4], o[4];
-            load4<float>(gamma + col, g);
-            load4<float>(beta + col, b);
+            float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + b[e];
+            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * gv[c][e] + bv[c][e];
             store4<T>(y + col, o);
         }
     }
@@ -68,12 +77,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int H, float eps) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float gv[NC][4], bv[NC][4];
+    load_feat<NC>(gamma, H, lane, gv);
+    load_feat<NC>(beta, H, lane, bv);
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
         float v[NC][4];
         load_row<T, NC>(x + (long)row * H, H, lane, v);
         float mu, rs;
         row_stats<NC>(v, H, lane, eps, mu, rs);
-        normalize_store<T, NC>(v, gamma, beta, y + (long)row * H, H, lane, mu, rs);
+        normalize_store<T, NC>(v, gv, bv, y + (long)row * H, H, lane, mu, rs);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
@@ -120,7 +132,7 @@ __device__ __forceinline__ void colacc_flush(const ColAcc<NC>& a, float* lds /*[
 }
 
 template <typename T, typename TDX, int NC>
-__device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dyrow, const float* gamma,
+__device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dyrow, const float (&gv)[NC][4],
                                            TDX* dxrow, int H, int lane, float mu, float rs, ColAcc<NC>& acc,
                                            int want_bias) {
     float dy[NC][4];
@@ -131,12 +143,10 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
     for (int c = 0; c < NC; ++c) {
         int col = (lane + 64 * c) * 4;
         if (col < H) {
-            float g[4];
-            load4<float>(gamma + col, g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xh[c][e] = (xv[c][e] - mu) * rs;
-                dxh[c][e] = dy[c][e] * g[e];
+                dxh[c][e] = dy[c][e] * gv[c][e];
                 s1 += dxh[c][e];
                 s2 += dxh[c][e] * xh[c][e];
                 acc.dg[c][e] += dy[c][e] * xh[c][e];
@@ -174,10 +184,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     ColAcc<NC> acc;
     colacc_zero(acc);
+    float gv[NC][4];
+    load_feat<NC>(gamma, H, lane, gv);
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
         float xv[NC][4];
         load_row<T, NC>(x + (long)row * H, H, lane, xv);
-        ln_bwd_row<T, T, NC>(xv, dy + (long)row * H, gamma, dx + (long)row * H, H, lane, mean[row], rstd[row], acc, want_bias);
+        ln_bwd_row<T, T, NC>(xv, dy + (long)row * H, gv, dx + (long)row * H, H, lane, mean[row], rstd[row], acc, want_bias);
     }
     colacc_flush(acc, lds, partial, H, lane, wid, want_bias);
 }
@@ -303,6 +315,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
                                                         int B, int S, int H, int vocab, int type_vocab, float eps) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int rows = B * S;
+    float gv[NC][4], bv[NC][4];
+    load_feat<NC>(gamma, H, lane, gv);
+    load_feat<NC>(beta, H, lane, bv);
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
         int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         int tt = tts ? tts[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
         gather_sum<T, NC>(word, pos, type, id, row % S, tt, H, lane, v);
         float mu, rs;
         row_stats<NC>(v, H, lane, eps, mu, rs);
-        normalize_store<T, NC>(v, gamma, beta, y + (long)row * H, H, lane, mu, rs);
+        normalize_store<T, NC>(v, gv, bv, y + (long)row * H, H, lane, mu, rs);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
@@ -330,12 +345,14 @@ __global__ __launch_bounds__(256) void embed_bwd_ln_kernel(const T* __restrict__
     const int rows = B * S;
     ColAcc<NC> acc;
     colacc_zero(acc);
+    float gv[NC][4];
+    load_feat<NC>(gamma, H, lane, gv);
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
         int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         int tt = tts ? tts[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
         float xv[NC][4];
         gather_sum<T, NC>(word, pos, type, id, row % S, tt, H, lane, xv);
-        ln_bwd_row<T, float, NC>(xv, dy + (long)row * H, gamma, de + (long)row * H, H, lane, mean[row], rstd[row], acc, 0);
+        ln_bwd_row<T, float, NC>(xv, dy + (long)row * H, gv, de + (long)row * H, H, lane, mean[row], rstd[row], acc, 0);
     }
     colacc_flush(acc, lds, partial, H, lane, wid, 0);
 }

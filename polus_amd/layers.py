@@ -151,10 +151,9 @@ class Dense(Layer):
             dy2 = du
         rows = x.shape[0]
         acc = ops.GEMM_ACCUM_C if accumulate else 0
-        ops.gemm(dy2, x, self.w.grad, a_layout=ops.K_STRIDED, b_layout=ops.K_STRIDED, flags=acc,
-                 split_k=dw_split_k(self.units, self.in_features, rows))
-        if self.b is not None:
-            ops.colsum(dy2, self.b.grad, accumulate=accumulate)
+        ops.dense_bwd_params(dy2.contiguous() if dy2.stride(1) != 1 else dy2, x, self.w.grad,
+                             self.b.grad if self.b is not None else None, accumulate,
+                             dw_split_k(self.units, self.in_features, rows))
         if not need_dx:
             return None
         dx = self._buf("dx", (rows, self.in_features), x.dtype, x.device)

@@ -139,16 +139,14 @@ class BertLayer:
                           self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate)
         ops.gemm(dz2, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, I, T))
         gemm_dx(dz2, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
-        ops.colsum(du, self.ffn1_b.grad, accumulate)
-        ops.gemm(du, bb["a1"], self.ffn1_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(I, H, T))
+        ops.dense_bwd_params(du, bb["a1"], self.ffn1_w.grad, self.ffn1_b.grad, accumulate, dw_split_k(I, H, T))
         gemm_dx(du, self.ffn1_w, da1, resid=dz2)
         ops.layernorm_bwd(da1, bb["z1"], self.ln1_g.value, bb["m1"], bb["r1"], dz1,
                           self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate)
         ops.gemm(dz1, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, H, T))
         gemm_dx(dz1, self.out_w, dctx)
         ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A)
-        ops.colsum(dqkv, self.qkv_b.grad, accumulate)
-        ops.gemm(dqkv, x, self.qkv_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(3 * H, H, T))
+        ops.dense_bwd_params(dqkv, x, self.qkv_w.grad, self.qkv_b.grad, accumulate, dw_split_k(3 * H, H, T))
         gemm_dx(dqkv, self.qkv_w, dx, resid=dz1)
         return dx
 

@@ -280,3 +280,25 @@ def transpose_bf16(src, dst):
     assert src.dtype == torch.bfloat16 and dst.dtype == torch.bfloat16 and dst.numel() == src.numel()
     assert src.is_contiguous() and dst.is_contiguous()
     check(_lib.load().polus_transpose_bf16(ptr(src), ptr(dst), R, C, _st()), "polus_transpose_bf16")
+
+
+def dense_bwd_params(dy, x, dw, db, accumulate=False, split_k=1):
+    """dW (+)= dY^T X and db (+)= colsum(dY) in one pass over dY."""
+    lib = _lib.load()
+    _req_cuda(dy, x, dw, db)
+    T, n_out = dy.shape
+    n_in = x.shape[1]
+    assert x.shape[0] == T and dw.shape == (n_out, n_in) and dw.dtype == torch.float32
+    assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+    nb = lib.polus_dense_bwd_params_workspace_bytes(T, n_out, n_in, split_k)
+    ws = workspace(dy.device).get(nb)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.polus_dense_bwd_params(dtype_code(dy.dtype), ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(dw), dw.stride(0),
+                                     ptr(db), T, n_out, n_in, int(accumulate), split_k, ptr(ws), nb, _st()),
+          "polus_dense_bwd_params")
+    if prof is not None:
+        e1.record()
+        prof.append(("dw", 2.0 * T * n_out * n_in, e0, e1))

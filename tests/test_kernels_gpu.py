@@ -519,3 +519,23 @@ def test_gemm_ring_mixed_layouts(ops, M, N, K, monkeypatch):
         ops.gemm(a_t, b_t, o1, a_layout=al, b_layout=bl)
         monkeypatch.delenv("POLUS_GEMM_V1")
         assert_close(host(out), host(o1), 1e-2, "ring vs 128x128")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,n_out,n_in,sk", [(4096, 768, 768, 7), (2048, 2304, 768, 3), (1000, 304, 136, 2),
+                                            (512, 10, 128, 1), (4096, 3072, 768, 1)])
+def test_dense_bwd_params(ops, dtype, T, n_out, n_in, sk):
+    """dW and db in one pass (bias gradient on the matrix pipe for the bf16 ring kernel)."""
+    r = rng(T + n_out + n_in)
+    dY, X = r.standard_normal((T, n_out)) * 0.1, r.standard_normal((T, n_in))
+    dy_t, x_t = dev(dY, dtype), dev(X, dtype)
+    dw = torch.full((n_out, n_in), float("nan"), device="cuda")
+    db = torch.full((n_out,), float("nan"), device="cuda")
+    ops.dense_bwd_params(dy_t, x_t, dw, db, split_k=sk)
+    tol = 3e-5 if dtype == torch.float32 else 2e-3
+    assert_close(host(dw), rounded(dY, dtype).T @ rounded(X, dtype), tol, "dW")
+    assert_close(host(db), rounded(dY, dtype).sum(0), 1e-4 if dtype == torch.float32 else 2e-3, "db")
+    w0, b0 = dw.clone(), db.clone()
+    ops.dense_bwd_params(dy_t, x_t, dw, db, accumulate=True, split_k=sk)
+    assert_close(host(dw), 2 * host(w0), 1e-6, "dW accumulate")
+    assert_close(host(db), 2 * host(b0), 1e-6, "db accumulate")

@@ -231,3 +231,65 @@ def test_ner_mlp_crf_step_matches_oracle():
     assert dec.shape == (B, S, C)
     ref_tags = ol.crf_viterbi(pot_ref, np.full(B, S), w[n[4]])
     assert np.array_equal(model.inference(x).cpu().numpy(), ref_tags)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_ir_dense_retrieval_trainer_step(mode):
+    """polus/ir/training.py:47-117: frozen encoders in forward_without_grads, trainable projections +
+    in-batch-negative scores; one Adam step checked against NumPy."""
+    from polus_amd.ir.models import DualEncoder
+    from polus_amd.ir.training import ContrastiveLoss, EfficientDenseRetrievalTrainer, InBatchDotScores
+    from polus_amd.models import BertConfig, BertModel
+    from polus_amd.optimizers import Adam
+    g, ocfg, params, _, _ = load_case("bert_small_b3_s48")
+    cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                     ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size)
+    enc = BertModel(cfg, compute_dtype=mode); enc.load_numpy_params(params)
+    B, S, E = 256, 16, 128           # B x B in-batch score matrix
+    r = np.random.Generator(np.random.PCG64(12))
+    q = {"input_ids": r.integers(1, ocfg.vocab_size, size=(B, S)).astype(np.int32), "attention_mask": np.ones((B, S), np.int32)}
+    d = {"input_ids": r.integers(1, ocfg.vocab_size, size=(B, S)).astype(np.int32), "attention_mask": np.ones((B, S), np.int32)}
+    model = DualEncoder(enc, projection_dim=E, compute_dtype=mode)
+    before = enc.arena.params.clone()
+    w = {v.name: v.numpy().astype(np.float64) for v in model.trainable_weights}
+    trainer = EfficientDenseRetrievalTrainer(model, InBatchDotScores(), optimizer=Adam(1e-3), loss=ContrastiveLoss())
+    assert str(trainer) == "SimilarityTrainer" and len(trainer.trainable_weights) == 4
+    loss = float(trainer.train_step(q, d))
+    assert torch.equal(before, enc.arena.params)            # no gradient reaches the encoders
+    # oracle: CLS states from the NumPy BERT, projections, scores, softmax CE on the diagonal
+    hq = ob.bert_fwd(params, ocfg, q["input_ids"], q["attention_mask"])[1]
+    hd = ob.bert_fwd(params, ocfg, d["input_ids"], d["attention_mask"])[1]
+    n = [v.name for v in model.trainable_weights]
+    wq, bq, wd, bd = (w[k] for k in n)
+    pq, pd_ = hq @ wq.T + bq, hd @ wd.T + bd
+    scores = pq @ pd_.T
+    loss_ref, ds = ol.sparse_softmax_xent_fwd(scores, np.arange(B))
+    assert abs(loss - loss_ref) < (1e-4 if mode == "f32" else 5e-2) * max(1.0, abs(loss_ref))
+    dq, dd = ds @ pd_, ds.T @ pq
+    got = {v.name: host(v.grad) for v in model.trainable_weights}
+    tol = 5e-4 if mode == "f32" else 8e-2
+    assert_close(got[n[0]], dq.T @ hq, tol, "query projection dW")
+    assert_close(got[n[1]], dq.sum(0), tol, "query projection db")
+    assert_close(got[n[2]], dd.T @ hd, tol, "document projection dW")
+
+
+def test_bert_large_shapes_one_layer():
+    """configs[3]: BERT-large geometry (H=1024, A=16, I=4096) through one layer, f32 engine vs oracle."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    ocfg = ob.BertConfig(200, 1024, 1, 16, 4096, 64, 2)
+    params, hw, hb = ob.golden_setup(ocfg, 3)
+    r = np.random.Generator(np.random.PCG64(2))
+    ids = r.integers(0, 200, size=(2, 40)).astype(np.int32)
+    mask = np.ones((2, 40), np.int32); mask[1, 25:] = 0
+    labels = r.integers(0, 3, size=(2, 40)).astype(np.int32)
+    model = build_model(ocfg, params, hw, hb, "f32")
+    loss_fn = SparseCategoricalCrossentropy()
+    logits = model(input_ids=ids, attention_mask=mask, training=True)
+    loss = float(loss_fn(labels, logits))
+    ref_loss, ref_logits, cache = ob.token_classifier_fwd(params, ocfg, hw, hb, ids, mask, labels)
+    assert abs(loss - ref_loss) < 2e-5
+    assert_close(host(logits), ref_logits, 1e-4, "logits")
+    model.backward(loss_fn.backward())
+    og = ob.token_classifier_bwd(params, ocfg, hw, cache)
+    for v in model.trainable_weights:
+        assert_close(host(v.grad), og[v.name], 2e-4, v.name)
