@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--large", action="store_true", help="BERT-large instead of BERT-base")
+    ap.add_argument("--dropout", type=float, default=0.1, help="hidden and attention dropout (HF BERT default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     args = ap.parse_args()
@@ -120,7 +121,8 @@ def main():
         H, A, I, L = 768, 12, 3072, args.layers
     B, S = args.batch, args.seq
     cfg = BertConfig(vocab_size=VOCAB, hidden_size=H, num_hidden_layers=L, num_attention_heads=A,
-                     intermediate_size=I, max_position_embeddings=512)
+                     intermediate_size=I, max_position_embeddings=512,
+                     hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
     model = BertModel(cfg, compute_dtype=args.dtype, num_labels=N_LABELS, seed=1234)
     total_steps = max(1000, args.steps + args.warmup)
     opt = AdamWeightDecay(learning_rate=warmup_scheduler(total_steps, 5e-5), weight_decay_rate=0.01)
@@ -194,7 +196,7 @@ def main():
             "config": {"workload": f"BERT-{'large' if args.large else 'base'} (L={L},H={H},A={A},I={I},V={VOCAB}) "
                                    f"token classification C={N_LABELS}, seq_len={S}, {B} samples/GPU "
                                    f"(BASELINE.json configs[2] per-GPU shape), AdamW lr 5e-5 wd 0.01 warm-up 10%, "
-                                   f"dropout 0.0, random-init weights",
+                                   f"dropout {args.dropout} (hidden + attention), random-init weights",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "grad_allreduce": "bucketed RCCL all-reduce (f32, 64 MB buckets) overlapped with backward" if world > 1 else "none"},
             "step_mfma_frac": round(sps / world * fstep / (PEAK_TFLOPS[args.dtype] * 1e12), 4),

@@ -42,7 +42,8 @@ enum { POLUS_ACT_NONE = 0, POLUS_ACT_GELU = 1, POLUS_ACT_SWISH = 2, POLUS_ACT_RE
 enum {
     POLUS_GEMM_ACCUM_C = 1,  /* C += result (gradient accumulation)                         */
     POLUS_GEMM_ACT_FWD = 2,  /* aux[m][n] = v (pre-activation, if aux != NULL); C = act(v)   */
-    POLUS_GEMM_ACT_BWD = 4   /* C = v * act'(aux[m][n])                                      */
+    POLUS_GEMM_ACT_BWD = 4,  /* C = v * act'(aux[m][n])                                      */
+    POLUS_GEMM_DROPOUT = 8   /* polus_gemm_dropout only: v = keep(seed, m*N+n) ? v/(1-p) : 0   */
 };
 
 const char* polus_last_error(void);
@@ -70,6 +71,20 @@ int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
                int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
                void* stream);
 
+/* polus_gemm with inverted dropout in the epilogue, applied after bias/activation and before the
+ * residual add (HF TFBertSelfOutput / TFBertOutput: dropout(dense(x)) + residual).  The mask is a
+ * pure function of (seed, m*N + n); polus_dropout_mask reproduces it. */
+int polus_gemm_dropout(int dtype, int a_layout, int b_layout, int c_dtype,
+                       const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                       int M, int N, int K, float alpha,
+                       const float* bias, const void* resid, long ldr, void* aux, long ldaux,
+                       int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
+                       float drop_p, uint32_t seed, void* stream);
+/* y[i] = keep(seed, i) ? x[i]/(1-p) : 0 (tf.keras.layers.Dropout; apply the same call to dy for backward) */
+int polus_dropout(int dtype, const void* x, void* y, int64_t n, float drop_p, uint32_t seed, void* stream);
+/* mask[i] = 1 if element i is kept (i = idx0 .. idx0+n-1): the reference for every dropout site */
+int polus_dropout_mask(uint32_t seed, float drop_p, uint32_t idx0, int64_t n, uint8_t* mask, void* stream);
+
 /* ---- Dense backward for the parameters (the dW/db part of tape.gradient, polus/training.py:185):
  * dW[n_out, n_in] (+)= dY[T, n_out]^T . X[T, n_in]  (f32) and, if db != NULL, db[n_out] (+)= column
  * sums of dY — one pass over dY (on the bf16 ring kernel the column sums ride on the matrix pipe).
@@ -87,27 +102,32 @@ int polus_dense_bwd_params(int dtype, const void* dY, long lddy, const void* X, 
  * mask  [B, S] int32 {0,1} (NULL = all ones)
  * ctx   [B*S, H]; lse [B, A, S] f32 = log-sum-exp of the masked, scaled scores
  * head_dim must be 64.  Backward recomputes the probabilities from lse; dqkv [B*S, 3H].
+ * drop_p > 0: inverted dropout of the probabilities after the softmax (HF attention_probs_dropout),
+ * mask = keep(seed, ((b*A+h)*S+q)*S+key), regenerated in backward.
  * workspace for bwd: B*A*S floats (row dot products dO.O). */
 int polus_attention_fwd(int dtype, const void* qkv, const int32_t* mask, void* ctx, float* lse,
-                        int B, int S, int n_heads, int head_dim, void* stream);
+                        int B, int S, int n_heads, int head_dim, float drop_p, uint32_t seed, void* stream);
 size_t polus_attention_bwd_workspace_bytes(int B, int S, int n_heads);
 int polus_attention_bwd(int dtype, const void* qkv, const int32_t* mask, const void* ctx,
                         const void* dctx, const float* lse, void* dqkv,
-                        int B, int S, int n_heads, int head_dim,
+                        int B, int S, int n_heads, int head_dim, float drop_p, uint32_t seed,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm over the feature axis, eps inside the sqrt, biased variance
  * (HF TFBertSelfOutput/TFBertOutput/TFBertEmbeddings LayerNorm, eps 1e-12).
  * fwd: y = (x-mean)*rstd*gamma+beta; mean/rstd [rows] f32 are saved for backward.
  * bwd: dx; dgamma/dbeta [H] f32 (+= when accumulate); if dbias != NULL also
- *      dbias[H] (+)= column sums of dx (the bias gradient of the Dense that produced x). */
+ *      dbias[H] (+)= column sums of dx (the bias gradient of the Dense that produced x).
+ *      When x = dropout(dense) + residual (drop_p > 0, mask index row*H+col as in polus_gemm_dropout):
+ *      dx_masked = dx * mask/(1-p) is the gradient the Dense sees, and dbias sums dx_masked. */
 size_t polus_layernorm_bwd_workspace_bytes(int rows, int H);
 int polus_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta,
                         void* y, float* mean, float* rstd, int rows, int H, float eps, void* stream);
 int polus_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                         const float* mean, const float* rstd, void* dx,
                         float* dgamma, float* dbeta, float* dbias, int accumulate,
-                        int rows, int H, void* workspace, size_t workspace_bytes, void* stream);
+                        int rows, int H, void* dx_masked, float drop_p, uint32_t seed,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- embeddings: word[ids] + pos[s] + type[tt] -> LayerNorm (HF TFBertEmbeddings; TF gather
  * has no padding_idx, so row 0 receives its gradient).  Tables and their gradients are f32.
@@ -118,13 +138,14 @@ int polus_embed_ln_fwd(int dtype, const int32_t* ids, const int32_t* type_ids,
                        const float* word, const float* pos, const float* type,
                        const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                        int B, int S, int H, int vocab, int max_pos, int type_vocab, float eps,
-                       void* stream);
+                       float drop_p, uint32_t seed, void* stream);
 int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids, const int32_t* type_ids,
                        const float* word, const float* pos, const float* type, const float* gamma,
                        const float* mean, const float* rstd,
                        float* gword, float* gpos, float* gtype, float* ggamma, float* gbeta,
                        int accumulate, int deterministic,
                        int B, int S, int H, int vocab, int max_pos, int type_vocab,
+                       float drop_p, uint32_t seed,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- column sums out[c] (+)= sum_r x[r][c]  (bias gradients) */

@@ -103,8 +103,9 @@ def additive_mask(attention_mask, dtype=np.float32):
     return ((1.0 - m) * MASK_VALUE).reshape(m.shape[0], 1, 1, m.shape[1]).astype(dtype)
 
 
-def attention_fwd(qkv, add_mask, n_heads):
-    """qkv [B,S,3H] fused; add_mask [B,1,1,S]. Returns ctx [B,S,H], probs [B,A,S,S]."""
+def attention_fwd(qkv, add_mask, n_heads, keep_scale=None):
+    """qkv [B,S,3H] fused; add_mask [B,1,1,S]. Returns ctx [B,S,H], probs [B,A,S,S].
+    keep_scale [B,A,S,S] = mask/(1-p): HF attention_probs_dropout, applied after the softmax."""
     B, S, H3 = qkv.shape
     H = H3 // 3
     d = H // n_heads
@@ -115,11 +116,12 @@ def attention_fwd(qkv, add_mask, n_heads):
     scores = scores - scores.max(-1, keepdims=True)
     e = np.exp(scores)
     probs = e / e.sum(-1, keepdims=True)
-    ctx = (probs @ v).transpose(0, 2, 1, 3).reshape(B, S, H)
+    pd = probs if keep_scale is None else probs * keep_scale
+    ctx = (pd @ v).transpose(0, 2, 1, 3).reshape(B, S, H)
     return ctx, probs
 
 
-def attention_bwd(dctx, qkv, probs, n_heads):
+def attention_bwd(dctx, qkv, probs, n_heads, keep_scale=None):
     B, S, H3 = qkv.shape
     H = H3 // 3
     d = H // n_heads
@@ -127,8 +129,11 @@ def attention_bwd(dctx, qkv, probs, n_heads):
     k = qkv[..., H:2 * H].reshape(B, S, n_heads, d).transpose(0, 2, 1, 3)
     v = qkv[..., 2 * H:].reshape(B, S, n_heads, d).transpose(0, 2, 1, 3)
     do = dctx.reshape(B, S, n_heads, d).transpose(0, 2, 1, 3)
-    dv = probs.transpose(0, 1, 3, 2) @ do
+    pd = probs if keep_scale is None else probs * keep_scale
+    dv = pd.transpose(0, 1, 3, 2) @ do
     dp = do @ v.transpose(0, 1, 3, 2)
+    if keep_scale is not None:
+        dp = dp * keep_scale
     ds = probs * (dp - (dp * probs).sum(-1, keepdims=True))
     ds = ds / math.sqrt(d)
     dq = ds @ k
@@ -182,17 +187,21 @@ def init_params(cfg, seed=1234, std=0.02, dtype=np.float32, with_embeddings=True
 
 # ----------------------------------------------------------------------------- model
 
-def embeddings_fwd(p, cfg, input_ids, token_type_ids=None):
+def embeddings_fwd(p, cfg, input_ids, token_type_ids=None, keep_scale=None):
     B, S = input_ids.shape
     if token_type_ids is None:
         token_type_ids = np.zeros_like(input_ids)
     e = p["emb.word"][input_ids] + p["emb.type"][token_type_ids] + p["emb.pos"][:S][None]
     y, mean, rstd = layer_norm_fwd(e, p["emb.ln.g"], p["emb.ln.b"], cfg.layer_norm_eps)
-    return y, (e, mean, rstd, input_ids, token_type_ids)
+    if keep_scale is not None:
+        y = y * keep_scale
+    return y, (e, mean, rstd, input_ids, token_type_ids, keep_scale)
 
 
 def embeddings_bwd(dy, p, cfg, cache):
-    e, mean, rstd, input_ids, token_type_ids = cache
+    e, mean, rstd, input_ids, token_type_ids, keep_scale = cache
+    if keep_scale is not None:
+        dy = dy * keep_scale
     de, dg, db = layer_norm_bwd(dy, e, p["emb.ln.g"], mean, rstd)
     g = {"emb.ln.g": dg, "emb.ln.b": db}
     gw = np.zeros_like(p["emb.word"])
@@ -205,45 +214,52 @@ def embeddings_bwd(dy, p, cfg, cache):
     return g
 
 
-def layer_fwd(p, cfg, i, x, add_mask):
+def layer_fwd(p, cfg, i, x, add_mask, drop=None):
+    """drop = dict(att=[B,A,S,S], h1=[B,S,H], h2=[B,S,H]) of keep-scales mask/(1-p), or None."""
     pre = f"layer{i}."
+    d = drop or {}
     qkv = linear_fwd(x, p[pre + "qkv.w"], p[pre + "qkv.b"])
-    ctx, probs = attention_fwd(qkv, add_mask, cfg.num_attention_heads)
-    z1 = linear_fwd(ctx, p[pre + "out.w"], p[pre + "out.b"]) + x
+    ctx, probs = attention_fwd(qkv, add_mask, cfg.num_attention_heads, d.get("att"))
+    o1 = linear_fwd(ctx, p[pre + "out.w"], p[pre + "out.b"])
+    z1 = (o1 if d.get("h1") is None else o1 * d["h1"]) + x
     a1, m1, r1 = layer_norm_fwd(z1, p[pre + "ln1.g"], p[pre + "ln1.b"], cfg.layer_norm_eps)
     u = linear_fwd(a1, p[pre + "ffn1.w"], p[pre + "ffn1.b"])
     f = gelu(u)
-    z2 = linear_fwd(f, p[pre + "ffn2.w"], p[pre + "ffn2.b"]) + a1
+    o2 = linear_fwd(f, p[pre + "ffn2.w"], p[pre + "ffn2.b"])
+    z2 = (o2 if d.get("h2") is None else o2 * d["h2"]) + a1
     y, m2, r2 = layer_norm_fwd(z2, p[pre + "ln2.g"], p[pre + "ln2.b"], cfg.layer_norm_eps)
     cache = dict(x=x, qkv=qkv, probs=probs, ctx=ctx, z1=z1, m1=m1, r1=r1, a1=a1,
-                 u=u, f=f, z2=z2, m2=m2, r2=r2)
+                 u=u, f=f, z2=z2, m2=m2, r2=r2, drop=d)
     return y, cache
 
 
 def layer_bwd(dy, p, cfg, i, c):
     pre = f"layer{i}."
     g = {}
+    d = c.get("drop") or {}
     dz2, g[pre + "ln2.g"], g[pre + "ln2.b"] = layer_norm_bwd(dy, c["z2"], p[pre + "ln2.g"], c["m2"], c["r2"])
-    df, g[pre + "ffn2.w"], g[pre + "ffn2.b"] = linear_bwd(dz2, c["f"], p[pre + "ffn2.w"])
+    dz2d = dz2 if d.get("h2") is None else dz2 * d["h2"]
+    df, g[pre + "ffn2.w"], g[pre + "ffn2.b"] = linear_bwd(dz2d, c["f"], p[pre + "ffn2.w"])
     du = df * gelu_grad(c["u"])
     da1, g[pre + "ffn1.w"], g[pre + "ffn1.b"] = linear_bwd(du, c["a1"], p[pre + "ffn1.w"])
     da1 = da1 + dz2
     dz1, g[pre + "ln1.g"], g[pre + "ln1.b"] = layer_norm_bwd(da1, c["z1"], p[pre + "ln1.g"], c["m1"], c["r1"])
-    dctx, g[pre + "out.w"], g[pre + "out.b"] = linear_bwd(dz1, c["ctx"], p[pre + "out.w"])
-    dqkv = attention_bwd(dctx, c["qkv"], c["probs"], cfg.num_attention_heads)
+    dz1d = dz1 if d.get("h1") is None else dz1 * d["h1"]
+    dctx, g[pre + "out.w"], g[pre + "out.b"] = linear_bwd(dz1d, c["ctx"], p[pre + "out.w"])
+    dqkv = attention_bwd(dctx, c["qkv"], c["probs"], cfg.num_attention_heads, d.get("att"))
     dx, g[pre + "qkv.w"], g[pre + "qkv.b"] = linear_bwd(dqkv, c["x"], p[pre + "qkv.w"])
     dx = dx + dz1
     return dx, g
 
 
-def encoder_fwd(p, cfg, hidden, attention_mask, layers=None):
+def encoder_fwd(p, cfg, hidden, attention_mask, layers=None, drop=None):
     """The TFBertSplited.call restatement (polus/models.py:197-216): runs `layers`
     (default: all) over `hidden` with the -10000 additive mask; returns
     (last_hidden_state, pooler_output=hidden[:,0,:], caches)."""
     add_mask = additive_mask(attention_mask, hidden.dtype)
     caches = []
     for i in (range(cfg.num_hidden_layers) if layers is None else layers):
-        hidden, c = layer_fwd(p, cfg, i, hidden, add_mask)
+        hidden, c = layer_fwd(p, cfg, i, hidden, add_mask, None if drop is None else drop["layers"][i])
         caches.append((i, c))
     return hidden, hidden[:, 0, :], caches
 
@@ -256,9 +272,10 @@ def encoder_bwd(dhidden, p, cfg, caches):
     return dhidden, grads
 
 
-def bert_fwd(p, cfg, input_ids, attention_mask, token_type_ids=None):
-    emb, ecache = embeddings_fwd(p, cfg, input_ids, token_type_ids)
-    last, pooled, caches = encoder_fwd(p, cfg, emb, attention_mask)
+def bert_fwd(p, cfg, input_ids, attention_mask, token_type_ids=None, drop=None):
+    """drop = dict(emb=[B,S,H], layers=[dict(att,h1,h2), ...]) of keep-scales, or None (dropout 0)."""
+    emb, ecache = embeddings_fwd(p, cfg, input_ids, token_type_ids, None if drop is None else drop["emb"])
+    last, pooled, caches = encoder_fwd(p, cfg, emb, attention_mask, drop=drop)
     return last, pooled, (ecache, caches)
 
 
@@ -272,12 +289,12 @@ def bert_bwd(dlast, p, cfg, cache):
 # ----------------------------------------------------------------------------- token classification
 
 def token_classifier_fwd(p, cfg, head_w, head_b, input_ids, attention_mask, labels,
-                         token_type_ids=None):
+                         token_type_ids=None, drop=None):
     """BERT + Dense(H->C) + sparse softmax CE (mean over every position), the
     ClassifierTrainer step shape of polus/training.py:366-397 with the Keras loss
     of tutorials/classifier_example.py:55."""
     from .losses import sparse_softmax_xent_fwd
-    last, _, cache = bert_fwd(p, cfg, input_ids, attention_mask, token_type_ids)
+    last, _, cache = bert_fwd(p, cfg, input_ids, attention_mask, token_type_ids, drop)
     logits = linear_fwd(last, head_w, head_b)
     loss, dlogits = sparse_softmax_xent_fwd(logits, labels)
     return loss, logits, (last, dlogits, cache)

@@ -15,7 +15,7 @@ ACT_NONE, ACT_GELU, ACT_SWISH, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 GEMM_ACCUM_C, GEMM_ACT_FWD, GEMM_ACT_BWD = 1, 2, 4
 
 _c = ctypes
-_vp, _i, _l, _f, _sz, _i64 = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t, _c.c_int64
+_vp, _i, _l, _f, _sz, _i64, _u32 = _c.c_void_p, _c.c_int, _c.c_long, _c.c_float, _c.c_size_t, _c.c_int64, _c.c_uint32
 
 # name -> (restype, argtypes); mirrors include/polus_hip.h one to one
 SIGNATURES = {
@@ -25,20 +25,24 @@ SIGNATURES = {
     "polus_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_gemm": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,
                         _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_gemm_dropout": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,
+                                _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp, _sz, _f, _u32, _vp]),
+    "polus_dropout_mask": (_i, [_u32, _f, _u32, _i64, _vp, _vp]),
+    "polus_dropout": (_i, [_i, _vp, _vp, _i64, _f, _u32, _vp]),
     "polus_dense_bwd_params_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "polus_dense_bwd_params": (_i, [_i, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "polus_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "polus_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32, _vp]),
     "polus_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "polus_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32, _vp, _sz, _vp]),
     "polus_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "polus_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "polus_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _u32, _vp, _sz, _vp]),
     "polus_embed_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_embed_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _i, _i, _i, _i, _i, _i, _f, _vp]),
+                                _i, _i, _i, _i, _i, _i, _f, _f, _u32, _vp]),
     "polus_embed_ln_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _i, _i,
-                                _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+                                _i, _i, _i, _i, _i, _i, _f, _u32, _vp, _sz, _vp]),
     "polus_colsum_workspace_bytes": (_sz, [_i, _i]),
     "polus_colsum": (_i, [_i, _vp, _l, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "polus_loss_workspace_bytes": (_sz, [_i]),

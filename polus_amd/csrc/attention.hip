@@ -110,6 +110,8 @@ struct AttnArgs {
     const void* dctx; const float* delta; void* dqkv;
     int B, S, A, H;
     float scale;
+    unsigned drop_thresh, drop_seed;   // attention-probability dropout; mask index ((b*A+h)*S+q)*S+key
+    float drop_inv;
 };
 
 __device__ __forceinline__ float key_bias(const int32_t* mask, int b, int S, int key) {
@@ -184,6 +186,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        if (p.drop_thresh) {   // the row sum above used the undropped probabilities (softmax first, then dropout)
+            const unsigned rowb = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb0 + 4 * g;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s[kt][r] = polus_keep(p.drop_seed, rowb + kt * 16 + r, p.drop_thresh) ? s[kt][r] * p.drop_inv : 0.f;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Frag<T> pb;
@@ -273,7 +283,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pr = __expf(s[kt][r] * p.scale + kbias[kt * 16 + 4 * g + r] - lse);
-                s[kt][r] = pr * (dp[kt][r] - dl) * p.scale;  // dS
+                float dpe = dp[kt][r];
+                if (p.drop_thresh) {
+                    const unsigned idx = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb0 + kt * 16 + 4 * g + r;
+                    dpe = polus_keep(p.drop_seed, idx, p.drop_thresh) ? dpe * p.drop_inv : 0.f;
+                }
+                s[kt][r] = pr * (dpe - dl) * p.scale;  // dS
             }
         }
 #pragma unroll
@@ -349,8 +364,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 int ql = qt * 16 + 4 * g + r;
                 float pr = __expf(s[qt][r] * p.scale + kb - slse[ql]);
-                dp[qt][r] = pr * (dp[qt][r] - sdelta[ql]) * p.scale;  // dS
-                s[qt][r] = pr;                                         // P
+                float dpe = dp[qt][r], pd = pr;
+                if (p.drop_thresh) {
+                    const unsigned idx = (((unsigned)b * p.A + h) * S + (unsigned)(qb0 + ql)) * S + (unsigned)key;
+                    const bool keep = polus_keep(p.drop_seed, idx, p.drop_thresh);
+                    dpe = keep ? dpe * p.drop_inv : 0.f;
+                    pd = keep ? pr * p.drop_inv : 0.f;
+                }
+                dp[qt][r] = pr * (dpe - sdelta[ql]) * p.scale;  // dS
+                s[qt][r] = pd;                                   // dropped P (what multiplied V forward)
             }
         }
 #pragma unroll
@@ -384,14 +406,16 @@ int check_common(const char* who, int dtype, int B, int S, int A, int hd) {
 }  // namespace
 
 extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* mask, void* ctx, float* lse,
-                                   int B, int S, int n_heads, int head_dim, void* stream) {
+                                   int B, int S, int n_heads, int head_dim, float drop_p, uint32_t seed, void* stream) {
     int rc = check_common("polus_attention_fwd", dtype, B, S, n_heads, head_dim);
     if (rc) return rc;
     POLUS_REQUIRE(qkv && ctx && lse, "polus_attention_fwd: null pointer");
     POLUS_REQUIRE(polus_aligned16(qkv) && polus_aligned16(ctx), "polus_attention_fwd: pointers must be 16-byte aligned");
     AttnArgs a = {};
+    POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)B * n_heads * S * S < (1LL << 32), "polus_attention_fwd: bad dropout arguments");
     a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.lse = lse;
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
+    a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p);
     dim3 grid((S + BLK - 1) / BLK, n_heads, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == POLUS_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
@@ -406,7 +430,7 @@ extern "C" size_t polus_attention_bwd_workspace_bytes(int B, int S, int n_heads)
 
 extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* mask, const void* ctx,
                                    const void* dctx, const float* lse, void* dqkv,
-                                   int B, int S, int n_heads, int head_dim,
+                                   int B, int S, int n_heads, int head_dim, float drop_p, uint32_t seed,
                                    void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_common("polus_attention_bwd", dtype, B, S, n_heads, head_dim);
     if (rc) return rc;
@@ -419,6 +443,8 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
     a.qkv = qkv; a.mask = mask; a.lse = const_cast<float*>(lse); a.dctx = dctx; a.dqkv = dqkv;
     a.delta = static_cast<const float*>(workspace);
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
+    POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "polus_attention_bwd: bad drop_p");
+    a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p);
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rows = B * S, dblocks = (rows + 3) / 4;
     if (dblocks > 4096) dblocks = 4096;

@@ -112,6 +112,25 @@ template <int N> __device__ __forceinline__ void apply_act_grad_n(int act, float
     }
 }
 
+// ---------------------------------------------------------------- dropout (counter-based)
+// keep(seed, idx) is a pure function of (seed, element index): forward and backward regenerate
+// the same mask instead of storing it.  murmur3 finaliser over idx ^ seed; the per-call seed
+// already mixes step / layer / site on the host.  thresh = p * 2^32.
+__device__ __forceinline__ uint32_t polus_hash32(uint32_t seed, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool polus_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
+    return polus_hash32(seed, idx) >= thresh;
+}
+static inline uint32_t polus_drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+}
+
 // ---------------------------------------------------------------- wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -38,7 +38,8 @@ template <> struct Cfg<float> {
     static constexpr int KS_STRIDE = 512, KS_SWZ = 6, LOG_RCH = 5;
 };
 
-template <typename T> union Chunk { uint4 u; T e[16 / sizeof(T)]; };
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T> union Chunk { uint4 u; u32x4_t w; T e[16 / sizeof(T)]; };
 
 // ---- HBM -> registers: one operand tile = 1024 16-byte chunks, 4 per thread.
 // Branch-free on purpose: a per-lane `if` around a global load makes hipcc wait vmcnt(0)
@@ -53,15 +54,17 @@ __device__ const uint4 g_zero_chunk[1] = {{0u, 0u, 0u, 0u}};
 template <typename T, bool VEC>
 __device__ __forceinline__ uint4 load_chunk(const T* __restrict__ base, long off, bool ok, int nvalid) {
     constexpr int EPC = Cfg<T>::EPC;
-    const T* zero = reinterpret_cast<const T*>(g_zero_chunk);
+    // both arms in the global address space: a generic-pointer select would turn into flat_load
+    typedef const __attribute__((address_space(1))) u32x4_t* gp16_t;
+    typedef const __attribute__((address_space(1))) T* gpe_t;
     Chunk<T> v;
     if (VEC) {
-        const T* p = ok ? base + off : zero;
-        v.u = *reinterpret_cast<const uint4*>(p);
+        gp16_t p = ok ? (gp16_t)(base + off) : (gp16_t)g_zero_chunk;
+        v.w = *p;
     } else {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const T* p = (ok && e < nvalid) ? base + off + e : zero;
+            gpe_t p = (ok && e < nvalid) ? (gpe_t)(base + off + e) : (gpe_t)g_zero_chunk;
             v.e[e] = *p;
         }
     }
@@ -258,12 +261,44 @@ extern "C" size_t polus_gemm_workspace_bytes(int M, int N, int split_k) {
     return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
 }
 
+static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
+                     const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                     int M, int N, int K, float alpha,
+                     const float* bias, const void* resid, long ldr, void* aux, long ldaux,
+                     int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
+                     float drop_p, uint32_t seed, void* stream);
+
 extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
                           const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                           int M, int N, int K, float alpha,
                           const float* bias, const void* resid, long ldr, void* aux, long ldaux,
                           int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
                           void* stream) {
+    POLUS_REQUIRE(!(flags & POLUS_GEMM_DROPOUT), "polus_gemm: use polus_gemm_dropout for POLUS_GEMM_DROPOUT");
+    return gemm_impl(dtype, a_layout, b_layout, c_dtype, A, lda, B, ldb, C, ldc, M, N, K, alpha, bias, resid, ldr,
+                     aux, ldaux, act, flags, split_k, workspace, workspace_bytes, 0.0f, 0u, stream);
+}
+
+extern "C" int polus_gemm_dropout(int dtype, int a_layout, int b_layout, int c_dtype,
+                                  const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                  int M, int N, int K, float alpha,
+                                  const float* bias, const void* resid, long ldr, void* aux, long ldaux,
+                                  int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
+                                  float drop_p, uint32_t seed, void* stream) {
+    POLUS_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "polus_gemm_dropout: need 0 <= p < 1 (got %f)", drop_p);
+    POLUS_REQUIRE(split_k <= 1, "polus_gemm_dropout: split_k is not supported with dropout");
+    POLUS_REQUIRE((long)M * N < (1LL << 32), "polus_gemm_dropout: M*N must fit 32 bits");
+    if (drop_p > 0.0f) flags |= POLUS_GEMM_DROPOUT; else flags &= ~POLUS_GEMM_DROPOUT;
+    return gemm_impl(dtype, a_layout, b_layout, c_dtype, A, lda, B, ldb, C, ldc, M, N, K, alpha, bias, resid, ldr,
+                     aux, ldaux, act, flags, split_k, workspace, workspace_bytes, drop_p, seed, stream);
+}
+
+static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
+                     const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                     int M, int N, int K, float alpha,
+                     const float* bias, const void* resid, long ldr, void* aux, long ldaux,
+                     int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
+                     float drop_p, uint32_t seed, void* stream) {
     POLUS_REQUIRE(dtype == POLUS_F32 || dtype == POLUS_BF16, "polus_gemm: bad dtype %d", dtype);
     POLUS_REQUIRE(c_dtype == POLUS_F32 || c_dtype == dtype, "polus_gemm: c_dtype must be f32 or dtype");
     POLUS_REQUIRE(M > 0 && N > 0 && K > 0, "polus_gemm: empty problem M=%d N=%d K=%d", M, N, K);
@@ -294,6 +329,7 @@ extern "C" int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
     a.k_per_split = ((nkt + split_k - 1) / split_k) * bk;
     a.bias = bias; a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = ldaux;
     a.act = act; a.flags = flags;
+    a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_thresh = polus_drop_thresh(drop_p); a.drop_seed = seed;
     a.partial = split_k > 1 ? static_cast<float*>(workspace) : nullptr;
     const int epc = (int)(16 / es);
     // whole-chunk validity: the contiguous extent of each operand must be a multiple of a chunk

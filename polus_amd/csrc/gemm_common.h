@@ -18,6 +18,8 @@ struct GemmArgs {
     float* partial;  // split-K slabs [splits][M][N] or null
     int a_vec, b_vec, epi_vec;
     int epi_vec16;   // C / resid / aux / bias rows allow 16-byte accesses at 8-column granularity
+    float drop_inv;       // 1/(1-p) when POLUS_GEMM_DROPOUT, mask index = m*N + n
+    unsigned drop_thresh, drop_seed;
     float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
@@ -68,6 +70,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4& ac
     if (p.flags & POLUS_GEMM_ACT_BWD) {
         float u[4]; ld4x<T>(static_cast<const T*>(p.aux) + (long)m * p.ldaux + n, u, ev, nvalid);
         apply_act_grad_n<4>(p.act, v, u);
+    }
+    if (p.flags & POLUS_GEMM_DROPOUT) {
+        const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = polus_keep(p.drop_seed, base + r, p.drop_thresh) ? v[r] * p.drop_inv : 0.0f;
     }
     if (p.resid) {
         float rr[4]; ld4x<T>(static_cast<const T*>(p.resid) + (long)m * p.ldr + n, rr, ev, nvalid);
@@ -170,6 +177,11 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
 #pragma unroll
                 for (int r = 0; r < 8; ++r) u[r] = (float)uu[ps][r];
                 apply_act_grad_n<8>(p.act, v, u);
+            }
+            if (p.flags & POLUS_GEMM_DROPOUT) {
+                const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = polus_keep(p.drop_seed, base + r, p.drop_thresh) ? v[r] * p.drop_inv : 0.0f;
             }
             if (resid) {
 #pragma unroll

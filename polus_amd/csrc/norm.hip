@@ -9,8 +9,9 @@
 namespace {
 
 constexpr int MAXC = 8;           // chunks of 256 features per row: H <= 2048 (template NC <= MAXC)
-constexpr int WAVES = 4;          // waves per workgroup
-constexpr int MAX_PARTIAL_BLOCKS = 1024;
+constexpr int WAVES = 16;         // waves per workgroup (1024 threads): 4096 waves at 256 workgroups
+constexpr int LN_THREADS = 64 * WAVES;
+constexpr int MAX_PARTIAL_BLOCKS = 256;   // per-feature partial sums [blocks][3][H] f32, flushed once per 64 rows
 
 __device__ __forceinline__ int n_chunks(int H) { return (H + 255) >> 8; }
 
@@ -58,21 +59,25 @@ __device__ __forceinline__ void row_stats(const float (&v)[NC][4], int H, int la
 
 template <typename T, int NC>
 __device__ __forceinline__ void normalize_store(const float (&v)[NC][4], const float (&gv)[NC][4], const float (&bv)[NC][4],
-                                                T* y, int H, int lane, float mean, float rstd) {
+                                                T* y, int H, int lane, float mean, float rstd,
+                                                unsigned dthresh = 0, unsigned dseed = 0, float dinv = 1.f, unsigned rowbase = 0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         int col = (lane + 64 * c) * 4;
         if (col < H) {
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * gv[c][e] + bv[c][e];
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[c][e] - mean) * rstd * gv[c][e] + bv[c][e];
+                if (dthresh) o[e] = polus_keep(dseed, rowbase + col + e, dthresh) ? o[e] * dinv : 0.f;
+            }
             store4<T>(y + col, o);
         }
     }
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int rows, int H, float eps) {
@@ -89,6 +94,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
+
+struct DropArgs { unsigned thresh, seed; float inv; };   // thresh == 0: no dropout
 
 // Shared tail of the LN backward kernels: given x-hat pieces and dy for one row, produce dx
 // and accumulate the per-feature sums.
@@ -134,9 +141,19 @@ __device__ __forceinline__ void colacc_flush(const ColAcc<NC>& a, float* lds /*[
 template <typename T, typename TDX, int NC>
 __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dyrow, const float (&gv)[NC][4],
                                            TDX* dxrow, int H, int lane, float mu, float rs, ColAcc<NC>& acc,
-                                           int want_bias) {
+                                           int want_bias, TDX* dxm_row = nullptr, DropArgs out_drop = DropArgs{0, 0, 1.f},
+                                           DropArgs in_drop = DropArgs{0, 0, 1.f}, unsigned rowbase = 0) {
     float dy[NC][4];
     load_row<T, NC>(dyrow, H, lane, dy);
+    if (in_drop.thresh) {   // y = dropout(LN(x)): the incoming gradient passes through the same mask
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            int col = (lane + 64 * c) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dy[c][e] = polus_keep(in_drop.seed, rowbase + col + e, in_drop.thresh) ? dy[c][e] * in_drop.inv : 0.f;
+        }
+    }
     float s1 = 0.f, s2 = 0.f;
     float xh[NC][4], dxh[NC][4];
 #pragma unroll
@@ -163,22 +180,26 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
     for (int c = 0; c < NC; ++c) {
         int col = (lane + 64 * c) * 4;
         if (col < H) {
-            float o[4];
+            float o[4], om[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 o[e] = (dxh[c][e] - s1 - xh[c][e] * s2) * rs;
-                if (want_bias) acc.dbias[c][e] += o[e];
+                // x = dropout(dense) + residual: the Dense (and its bias) see the masked gradient
+                om[e] = out_drop.thresh ? (polus_keep(out_drop.seed, rowbase + col + e, out_drop.thresh) ? o[e] * out_drop.inv : 0.f) : o[e];
+                if (want_bias) acc.dbias[c][e] += om[e];
             }
             store4<TDX>(dxrow + col, o);
+            if (dxm_row) store4<TDX>(dxm_row + col, om);
         }
     }
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
-                                                     float* __restrict__ partial, int rows, int H, int want_bias) {
+                                                     float* __restrict__ partial, int rows, int H, int want_bias,
+                                                     T* __restrict__ dxm, DropArgs drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -189,7 +210,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
         float xv[NC][4];
         load_row<T, NC>(x + (long)row * H, H, lane, xv);
-        ln_bwd_row<T, T, NC>(xv, dy + (long)row * H, gv, dx + (long)row * H, H, lane, mean[row], rstd[row], acc, want_bias);
+        ln_bwd_row<T, T, NC>(xv, dy + (long)row * H, gv, dx + (long)row * H, H, lane, mean[row], rstd[row], acc, want_bias,
+                             dxm ? dxm + (long)row * H : nullptr, drop, DropArgs{0, 0, 1.f}, (unsigned)row * (unsigned)H);
     }
     colacc_flush(acc, lds, partial, H, lane, wid, want_bias);
 }
@@ -307,12 +329,13 @@ __device__ __forceinline__ void gather_sum(const float* word, const float* pos, 
 }
 
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tts,
+__global__ __launch_bounds__(LN_THREADS) void embed_fwd_kernel(const int32_t* __restrict__ ids, const int32_t* __restrict__ tts,
                                                         const float* __restrict__ word, const float* __restrict__ pos,
                                                         const float* __restrict__ type, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
-                                                        int B, int S, int H, int vocab, int type_vocab, float eps) {
+                                                        int B, int S, int H, int vocab, int type_vocab, float eps,
+                                                        unsigned dthresh, unsigned dseed, float dinv) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int rows = B * S;
     float gv[NC][4], bv[NC][4];
@@ -325,20 +348,20 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
         gather_sum<T, NC>(word, pos, type, id, row % S, tt, H, lane, v);
         float mu, rs;
         row_stats<NC>(v, H, lane, eps, mu, rs);
-        normalize_store<T, NC>(v, gv, bv, y + (long)row * H, H, lane, mu, rs);
+        normalize_store<T, NC>(v, gv, bv, y + (long)row * H, H, lane, mu, rs, dthresh, dseed, dinv, (unsigned)row * (unsigned)H);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
 
 // LN backward of the embedding sum: de (f32 workspace) + gamma/beta partials
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void embed_bwd_ln_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(LN_THREADS) void embed_bwd_ln_kernel(const T* __restrict__ dy, const int32_t* __restrict__ ids,
                                                            const int32_t* __restrict__ tts, const float* __restrict__ word,
                                                            const float* __restrict__ pos, const float* __restrict__ type,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float* __restrict__ de,
                                                            float* __restrict__ partial, int B, int S, int H, int vocab,
-                                                           int type_vocab) {
+                                                           int type_vocab, DropArgs in_drop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -352,14 +375,15 @@ __global__ __launch_bounds__(256) void embed_bwd_ln_kernel(const T* __restrict__
         int tt = tts ? tts[row] : 0; tt = tt < 0 ? 0 : (tt >= type_vocab ? type_vocab - 1 : tt);
         float xv[NC][4];
         gather_sum<T, NC>(word, pos, type, id, row % S, tt, H, lane, xv);
-        ln_bwd_row<T, float, NC>(xv, dy + (long)row * H, gv, de + (long)row * H, H, lane, mean[row], rstd[row], acc, 0);
+        ln_bwd_row<T, float, NC>(xv, dy + (long)row * H, gv, de + (long)row * H, H, lane, mean[row], rstd[row], acc, 0,
+                                 nullptr, DropArgs{0, 0, 1.f}, in_drop, (unsigned)row * (unsigned)H);
     }
     colacc_flush(acc, lds, partial, H, lane, wid, 0);
 }
 
 // word-table gradient, atomic form: one wave per token, 256 contiguous bytes per
 // wave-instruction (the shape global f32 atomics run at full rate for)
-__global__ __launch_bounds__(256) void embed_scatter_atomic_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(LN_THREADS) void embed_scatter_atomic_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
                                                                    float* __restrict__ gword, int rows, int H, int vocab) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256) void embed_scatter_atomic_kernel(const float* 
 
 // word-table gradient, reproducible form: the first occurrence of an id owns it and adds
 // the rows of every occurrence in token order.
-__global__ __launch_bounds__(256) void embed_scatter_owner_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
+__global__ __launch_bounds__(LN_THREADS) void embed_scatter_owner_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
                                                                   float* __restrict__ gword, int rows, int H, int vocab) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
@@ -440,9 +464,9 @@ extern "C" int polus_layernorm_fwd(int dtype, const void* x, const float* gamma,
     int blocks = (rows + WAVES - 1) / WAVES;
     if (blocks > 4096) blocks = 4096;
     if (dtype == POLUS_BF16)
-        POLUS_NC_DISPATCH(H, bf16_t, ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        POLUS_NC_DISPATCH(H, bf16_t, ln_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
     else if (dtype == POLUS_F32)
-        POLUS_NC_DISPATCH(H, float, ln_fwd_kernel, dim3(blocks), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, H, eps);
+        POLUS_NC_DISPATCH(H, float, ln_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, H, eps);
     else POLUS_FAIL("polus_layernorm_fwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_layernorm_fwd");
     return POLUS_OK;
@@ -451,8 +475,12 @@ extern "C" int polus_layernorm_fwd(int dtype, const void* x, const float* gamma,
 extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma,
                                    const float* mean, const float* rstd, void* dx,
                                    float* dgamma, float* dbeta, float* dbias, int accumulate,
-                                   int rows, int H, void* workspace, size_t workspace_bytes, void* stream) {
+                                   int rows, int H, void* dx_masked, float drop_p, uint32_t seed,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     POLUS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "polus_layernorm_bwd: null pointer");
+    POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)rows * H < (1LL << 32), "polus_layernorm_bwd: bad dropout arguments");
+    POLUS_REQUIRE(!(drop_p > 0.f) || dx_masked, "polus_layernorm_bwd: dropout needs dx_masked");
+    DropArgs drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p)};
     POLUS_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 256 * MAXC, "polus_layernorm_bwd: bad H=%d", H);
     POLUS_REQUIRE(polus_aligned16(x) && polus_aligned16(dy) && polus_aligned16(dx) && polus_aligned16(gamma),
                   "polus_layernorm_bwd: pointers must be 16-byte aligned");
@@ -464,9 +492,9 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
     size_t lds = 3 * (size_t)H * sizeof(float);
     int wb = dbias ? 1 : 0;
     if (dtype == POLUS_BF16)
-        POLUS_NC_DISPATCH(H, bf16_t, ln_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb);
+        POLUS_NC_DISPATCH(H, bf16_t, ln_bwd_kernel, dim3(blocks), dim3(LN_THREADS), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb, (bf16_t*)dx_masked, drop);
     else if (dtype == POLUS_F32)
-        POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(256), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb);
+        POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(LN_THREADS), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb, (float*)dx_masked, drop);
     else POLUS_FAIL("polus_layernorm_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd");
     int ncols = (wb ? 3 : 2) * H;
@@ -503,8 +531,11 @@ extern "C" int polus_embed_ln_fwd(int dtype, const int32_t* ids, const int32_t* 
                                   const float* word, const float* pos, const float* type,
                                   const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                   int B, int S, int H, int vocab, int max_pos, int type_vocab, float eps,
-                                  void* stream) {
+                                  float drop_p, uint32_t seed, void* stream) {
     POLUS_REQUIRE(ids && word && pos && type && gamma && beta && y && mean && rstd, "polus_embed_ln_fwd: null pointer");
+    POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "polus_embed_ln_fwd: bad drop_p");
+    const unsigned dthresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u;
+    const float dinv = 1.0f / (1.0f - drop_p);
     POLUS_REQUIRE(B > 0 && S > 0 && S <= max_pos, "polus_embed_ln_fwd: S=%d exceeds max_position_embeddings=%d", S, max_pos);
     POLUS_REQUIRE(H % 4 == 0 && H <= 256 * MAXC && vocab > 0 && type_vocab > 0, "polus_embed_ln_fwd: bad H=%d", H);
     POLUS_REQUIRE(polus_aligned16(word) && polus_aligned16(pos) && polus_aligned16(type) && polus_aligned16(y) &&
@@ -513,9 +544,9 @@ extern "C" int polus_embed_ln_fwd(int dtype, const int32_t* ids, const int32_t* 
     int rows = B * S, blocks = (rows + WAVES - 1) / WAVES;
     if (blocks > 4096) blocks = 4096;
     if (dtype == POLUS_BF16)
-        POLUS_NC_DISPATCH(H, bf16_t, embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, ids, type_ids, word, pos, type, gamma, beta, (bf16_t*)y, mean, rstd, B, S, H, vocab, type_vocab, eps);
+        POLUS_NC_DISPATCH(H, bf16_t, embed_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, ids, type_ids, word, pos, type, gamma, beta, (bf16_t*)y, mean, rstd, B, S, H, vocab, type_vocab, eps, dthresh, seed, dinv);
     else if (dtype == POLUS_F32)
-        POLUS_NC_DISPATCH(H, float, embed_fwd_kernel, dim3(blocks), dim3(256), 0, st, ids, type_ids, word, pos, type, gamma, beta, (float*)y, mean, rstd, B, S, H, vocab, type_vocab, eps);
+        POLUS_NC_DISPATCH(H, float, embed_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, ids, type_ids, word, pos, type, gamma, beta, (float*)y, mean, rstd, B, S, H, vocab, type_vocab, eps, dthresh, seed, dinv);
     else POLUS_FAIL("polus_embed_ln_fwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_embed_ln_fwd");
     return POLUS_OK;
@@ -527,7 +558,9 @@ extern "C" int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids,
                                   float* gword, float* gpos, float* gtype, float* ggamma, float* gbeta,
                                   int accumulate, int deterministic,
                                   int B, int S, int H, int vocab, int max_pos, int type_vocab,
+                                  float drop_p, uint32_t seed,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+    DropArgs in_drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p)};
     POLUS_REQUIRE(dy && ids && word && pos && type && gamma && mean && rstd && gword && gpos && gtype && ggamma && gbeta,
                   "polus_embed_ln_bwd: null pointer");
     POLUS_REQUIRE(B > 0 && S > 0 && S <= max_pos && H % 4 == 0 && H <= 256 * MAXC, "polus_embed_ln_bwd: bad shape");
@@ -544,9 +577,9 @@ extern "C" int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids,
     int blocks = ln_blocks(rows);
     size_t lds = 3 * (size_t)H * sizeof(float);
     if (dtype == POLUS_BF16)
-        POLUS_NC_DISPATCH(H, bf16_t, embed_bwd_ln_kernel, dim3(blocks), dim3(256), lds, st, (const bf16_t*)dy, ids, type_ids, word, pos, type, gamma, mean, rstd, de, partial, B, S, H, vocab, type_vocab);
+        POLUS_NC_DISPATCH(H, bf16_t, embed_bwd_ln_kernel, dim3(blocks), dim3(LN_THREADS), lds, st, (const bf16_t*)dy, ids, type_ids, word, pos, type, gamma, mean, rstd, de, partial, B, S, H, vocab, type_vocab, in_drop);
     else if (dtype == POLUS_F32)
-        POLUS_NC_DISPATCH(H, float, embed_bwd_ln_kernel, dim3(blocks), dim3(256), lds, st, (const float*)dy, ids, type_ids, word, pos, type, gamma, mean, rstd, de, partial, B, S, H, vocab, type_vocab);
+        POLUS_NC_DISPATCH(H, float, embed_bwd_ln_kernel, dim3(blocks), dim3(LN_THREADS), lds, st, (const float*)dy, ids, type_ids, word, pos, type, gamma, mean, rstd, de, partial, B, S, H, vocab, type_vocab, in_drop);
     else POLUS_FAIL("polus_embed_ln_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(ln)");
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((2 * H + 63) / 64), dim3(1024), 0, st,
@@ -560,9 +593,9 @@ extern "C" int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids,
     int sblocks = (rows + WAVES - 1) / WAVES;
     if (sblocks > 4096) sblocks = 4096;
     if (deterministic)
-        hipLaunchKernelGGL(embed_scatter_owner_kernel, dim3(sblocks), dim3(256), 0, st, de, ids, gword, rows, H, vocab);
+        hipLaunchKernelGGL(embed_scatter_owner_kernel, dim3(sblocks), dim3(LN_THREADS), 0, st, de, ids, gword, rows, H, vocab);
     else
-        hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(sblocks), dim3(256), 0, st, de, ids, gword, rows, H, vocab);
+        hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(sblocks), dim3(LN_THREADS), 0, st, de, ids, gword, rows, H, vocab);
     POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(scatter)");
     hipLaunchKernelGGL(embed_pos_grad_kernel, dim3(((long)S * H + 255) / 256), dim3(256), 0, st, de, gpos, B, S, H, accumulate);
     POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(pos)");

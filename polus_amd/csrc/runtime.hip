@@ -93,6 +93,19 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
     }
 }
 
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, unsigned seed, unsigned thresh, float inv) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = polus_keep(seed, (unsigned)i, thresh) ? from_f<T>(to_f<T>(x[i]) * inv) : from_f<T>(0.f);
+}
+
+__global__ void dropout_mask_kernel(unsigned seed, unsigned thresh, unsigned idx0, int64_t n, uint8_t* __restrict__ mask) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) mask[i] = polus_keep(seed, idx0 + (unsigned)i, thresh) ? 1 : 0;
+}
+
 inline int stream_grid(int64_t n) {
     int64_t b = (n / 4 + 255) / 256;
     if (b < 1) b = 1;
@@ -154,5 +167,31 @@ extern "C" int polus_transpose_bf16(const void* src, void* dst, int rows, int co
     hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream),
                        (const unsigned short*)src, (unsigned short*)dst, rows, cols);
     POLUS_CHECK_LAUNCH("polus_transpose_bf16");
+    return POLUS_OK;
+}
+
+extern "C" int polus_dropout_mask(uint32_t seed, float drop_p, uint32_t idx0, int64_t n, uint8_t* mask, void* stream) {
+    POLUS_REQUIRE(mask && n >= 0 && drop_p >= 0.0f && drop_p < 1.0f, "polus_dropout_mask: bad arguments");
+    if (n == 0) return POLUS_OK;
+    int64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)b), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       seed, polus_drop_thresh(drop_p), idx0, n, mask);
+    POLUS_CHECK_LAUNCH("polus_dropout_mask");
+    return POLUS_OK;
+}
+
+extern "C" int polus_dropout(int dtype, const void* x, void* y, int64_t n, float drop_p, uint32_t seed, void* stream) {
+    POLUS_REQUIRE(x && y && n >= 0 && n < (1LL << 32) && drop_p >= 0.0f && drop_p < 1.0f, "polus_dropout: bad arguments");
+    if (n == 0) return POLUS_OK;
+    int64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned th = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u;
+    const float inv = 1.0f / (1.0f - drop_p);
+    if (dtype == POLUS_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((int)b), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n, seed, th, inv);
+    else if (dtype == POLUS_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((int)b), dim3(256), 0, st, (const float*)x, (float*)y, n, seed, th, inv);
+    else POLUS_FAIL("polus_dropout: bad dtype");
+    POLUS_CHECK_LAUNCH("polus_dropout");
     return POLUS_OK;
 }

@@ -79,18 +79,38 @@ class Flatten(Layer):
 
 
 class Dropout(Layer):
-    """Inverted dropout. rate 0 (the parity configuration) is the identity."""
+    """tf.keras.layers.Dropout: inverted dropout in training, identity otherwise.  The mask is a
+    hash of (seed, element index) regenerated in backward; the seed advances every training call."""
+    _instances = 0
 
-    def __init__(self, rate=0.0, input_shape=None):
+    def __init__(self, rate=0.0, input_shape=None, seed=None):
         self.rate = float(rate)
-        if self.rate != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented in this round (see DESIGN.md, out of scope)")
+        if not 0.0 <= self.rate < 1.0:
+            raise ValueError("dropout rate must be in [0, 1)")
+        Dropout._instances += 1
+        self.seed = (seed if seed is not None else 7919 * Dropout._instances) & 0xFFFFFFFF
+        self.calls = 0
+        self._active = None
 
     def forward(self, x, training=False):
-        return x
+        if not training or self.rate == 0.0:
+            self._active = None
+            return x
+        self.calls += 1
+        s = (self.seed + 0x9E3779B1 * self.calls) & 0xFFFFFFFF
+        xc = x.contiguous()
+        y = self._buf("y", xc.shape, xc.dtype, xc.device)
+        ops.dropout(xc, y, self.rate, s)
+        self._active = s
+        return y
 
     def backward(self, dy, accumulate=False):
-        return dy
+        if self._active is None:
+            return dy
+        dyc = dy.contiguous()
+        dx = self._buf("dx", dyc.shape, dyc.dtype, dyc.device)
+        ops.dropout(dyc, dx, self.rate, self._active)
+        return dx
 
 
 class Dense(Layer):

@@ -29,8 +29,8 @@ class BertConfig:
                  hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, _name_or_path=""):
         if hidden_size != num_attention_heads * 64:
             raise ValueError("the fused attention kernel is built for head_dim 64 (BERT-base/large, BioBERT, PubMedBERT)")
-        if hidden_dropout_prob or attention_probs_dropout_prob:
-            raise NotImplementedError("dropout > 0 is not implemented in this round (DESIGN.md, out of scope)")
+        if not (0.0 <= hidden_dropout_prob < 1.0 and 0.0 <= attention_probs_dropout_prob < 1.0):
+            raise ValueError("dropout probabilities must be in [0, 1)")
         self.vocab_size, self.hidden_size = vocab_size, hidden_size
         self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
         self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
@@ -60,6 +60,14 @@ class BaseModelOutputWithPooling:
         if isinstance(k, int):
             return (self.last_hidden_state, self.pooler_output)[k]
         return getattr(self, k)
+
+
+def dropout_seed(base, step, layer, site):
+    """32-bit seed of one dropout site of one step (sites: 0 attention probs, 1 attention output,
+    2 FFN output; layer -1 = embeddings).  The kernels hash (seed, element index)."""
+    x = (base * 0x9E3779B1 + step * 0x85EBCA6B + ((layer + 1) * 8 + site) * 0xC2B2AE35) & 0xFFFFFFFF
+    x ^= x >> 15
+    return (x * 0x2C1B3C6D) & 0xFFFFFFFF
 
 
 def _trunc_normal(rng, shape, std=0.02):
@@ -100,7 +108,7 @@ class BertLayer:
             t = self._bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=dev)
         return t
 
-    def forward(self, x, mask, B, S):
+    def forward(self, x, mask, B, S, p_hid=0.0, p_att=0.0, seeds=(0, 0, 0)):
         cfg = self.cfg
         H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         T, dt, dev = B * S, x.dtype, x.device
@@ -112,13 +120,13 @@ class BertLayer:
         z2, y = b("z2", (T, H)), b("y", (T, H))
         m2, r2 = b("m2", (T,), torch.float32), b("r2", (T,), torch.float32)
         ops.gemm(x, self.qkv_w.compute, qkv, bias=self.qkv_b.value)
-        ops.attention_fwd(qkv, mask, ctx, lse, B, S, A)
-        ops.gemm(ctx, self.out_w.compute, z1, bias=self.out_b.value, resid=x)
+        ops.attention_fwd(qkv, mask, ctx, lse, B, S, A, drop_p=p_att, seed=seeds[0])
+        ops.gemm(ctx, self.out_w.compute, z1, bias=self.out_b.value, resid=x, drop_p=p_hid, seed=seeds[1])
         ops.layernorm_fwd(z1, self.ln1_g.value, self.ln1_b.value, a1, m1, r1, cfg.layer_norm_eps)
         ops.gemm(a1, self.ffn1_w.compute, f, bias=self.ffn1_b.value, aux=u, act="gelu", flags=ops.GEMM_ACT_FWD)
-        ops.gemm(f, self.ffn2_w.compute, z2, bias=self.ffn2_b.value, resid=a1)
+        ops.gemm(f, self.ffn2_w.compute, z2, bias=self.ffn2_b.value, resid=a1, drop_p=p_hid, seed=seeds[2])
         ops.layernorm_fwd(z2, self.ln2_g.value, self.ln2_b.value, y, m2, r2, cfg.layer_norm_eps)
-        self._stash = (x, mask, B, S)
+        self._stash = (x, mask, B, S, p_hid, p_att, seeds)
         return y
 
     def backward(self, dy, scratch, accumulate=False):
@@ -126,7 +134,7 @@ class BertLayer:
         to when `accumulate`).  `scratch(key, shape)` hands out buffers shared by all layers."""
         cfg = self.cfg
         H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
-        x, mask, B, S = self._stash
+        x, mask, B, S, p_hid, p_att, seeds = self._stash
         T = B * S
         bb = self._bufs
         acc = ops.GEMM_ACCUM_C if accumulate else 0
@@ -135,17 +143,24 @@ class BertLayer:
         da1, dz1 = scratch("da1", (T, H)), scratch("dz1", (T, H))
         dctx, dqkv = scratch("dctx", (T, H)), scratch("dqkv", (T, 3 * H))
         dx = scratch("dx%d" % (self.index & 1), (T, H))
+        # z2 = dropout(ffn2(f)) + a1: the residual path takes dz2, the Dense path dz2 * mask/(1-p)
+        dz2m = scratch("dz2m", (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(dy, bb["z2"], self.ln2_g.value, bb["m2"], bb["r2"], dz2,
-                          self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate)
-        ops.gemm(dz2, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, I, T))
-        gemm_dx(dz2, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
+                          self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate,
+                          dx_masked=dz2m, drop_p=p_hid, seed=seeds[2])
+        dz2d = dz2m if dz2m is not None else dz2
+        ops.gemm(dz2d, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, I, T))
+        gemm_dx(dz2d, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
         ops.dense_bwd_params(du, bb["a1"], self.ffn1_w.grad, self.ffn1_b.grad, accumulate, dw_split_k(I, H, T))
         gemm_dx(du, self.ffn1_w, da1, resid=dz2)
+        dz1m = scratch("dz1m", (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(da1, bb["z1"], self.ln1_g.value, bb["m1"], bb["r1"], dz1,
-                          self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate)
-        ops.gemm(dz1, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, H, T))
-        gemm_dx(dz1, self.out_w, dctx)
-        ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A)
+                          self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate,
+                          dx_masked=dz1m, drop_p=p_hid, seed=seeds[1])
+        dz1d = dz1m if dz1m is not None else dz1
+        ops.gemm(dz1d, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, H, T))
+        gemm_dx(dz1d, self.out_w, dctx)
+        ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A, drop_p=p_att, seed=seeds[0])
         ops.dense_bwd_params(dqkv, x, self.qkv_w.grad, self.qkv_b.grad, accumulate, dw_split_k(3 * H, H, T))
         gemm_dx(dqkv, self.qkv_w, dx, resid=dz1)
         return dx
@@ -165,7 +180,7 @@ class BertEmbeddings:
     def variables(self):
         return [self.word, self.pos, self.type, self.ln_g, self.ln_b]
 
-    def forward(self, input_ids, token_type_ids, dtype):
+    def forward(self, input_ids, token_type_ids, dtype, p_hid=0.0, seed=0):
         B, S = input_ids.shape
         dev = input_ids.device
         key = (B, S, dtype)
@@ -176,16 +191,18 @@ class BertEmbeddings:
                           "rstd": torch.empty(B * S, dtype=torch.float32, device=dev)}
         bb = self._bufs
         ops.embed_ln_fwd(input_ids, token_type_ids, self.word.value, self.pos.value, self.type.value,
-                         self.ln_g.value, self.ln_b.value, bb["y"], bb["mean"], bb["rstd"], self.cfg.layer_norm_eps)
-        self._stash = (input_ids, token_type_ids)
+                         self.ln_g.value, self.ln_b.value, bb["y"], bb["mean"], bb["rstd"], self.cfg.layer_norm_eps,
+                         drop_p=p_hid, seed=seed)
+        self._stash = (input_ids, token_type_ids, p_hid, seed)
         return bb["y"]
 
     def backward(self, dy, accumulate=False, deterministic=False):
-        ids, tts = self._stash
+        ids, tts, p_hid, seed = self._stash
         bb = self._bufs
         ops.embed_ln_bwd(dy, ids, tts, self.word.value, self.pos.value, self.type.value, self.ln_g.value,
                          bb["mean"], bb["rstd"], self.word.grad, self.pos.grad, self.type.grad,
-                         self.ln_g.grad, self.ln_b.grad, accumulate=accumulate, deterministic=deterministic)
+                         self.ln_g.grad, self.ln_b.grad, accumulate=accumulate, deterministic=deterministic,
+                         drop_p=p_hid, seed=seed)
 
 
 # ------------------------------------------------------------------------------------ model wrappers
@@ -329,6 +346,8 @@ class BertModel(PolusModel):
         if own:
             self.arena.finalize()
         self._scratch = {}
+        self.dropout_base_seed = seed
+        self.dropout_step = 0     # advanced once per training forward: fresh masks every step
 
     def scratch(self, key, shape):
         t = self._scratch.get(key)
@@ -345,9 +364,16 @@ class BertModel(PolusModel):
             self.head.w.assign(head_w)
             self.head.b.assign(head_b)
 
-    def encode(self, hidden, attention_mask, B, S):
+    def site_seed(self, layer, site, step=None):
+        return dropout_seed(self.dropout_base_seed, self.dropout_step if step is None else step, layer, site)
+
+    def encode(self, hidden, attention_mask, B, S, training=False):
+        cfg = self.config
+        p_hid = cfg.hidden_dropout_prob if training else 0.0
+        p_att = cfg.attention_probs_dropout_prob if training else 0.0
         for l in self.layer:
-            hidden = l.forward(hidden, attention_mask, B, S)
+            seeds = tuple(self.site_seed(l.index, k) for k in range(3))
+            hidden = l.forward(hidden, attention_mask, B, S, p_hid, p_att, seeds)
         return hidden
 
     def call(self, input_ids=None, attention_mask=None, token_type_ids=None, training=False, hidden_states=None, **kw):
@@ -363,13 +389,16 @@ class BertModel(PolusModel):
             B, S = input_ids.shape
             if token_type_ids is not None:
                 token_type_ids = to_device(token_type_ids, torch.int32, dev)
-            hidden = self.embeddings.forward(input_ids, token_type_ids, self.compute_dtype)
+            hidden = self.embeddings.forward(input_ids, token_type_ids, self.compute_dtype,
+                                             self.config.hidden_dropout_prob if training else 0.0, self.site_seed(-1, 0))
         else:
             hs = to_device(hidden_states, self.compute_dtype, dev)
             B, S = hs.shape[0], hs.shape[1]
             hidden = hs.reshape(B * S, -1)
         self._shape = (B, S)
-        hidden = self.encode(hidden, attention_mask, B, S)
+        hidden = self.encode(hidden, attention_mask, B, S, training)
+        if training:
+            self.dropout_step += 1
         H = self.config.hidden_size
         if self.head is not None:
             return self.head.forward(hidden).view(B, S, -1)
@@ -414,8 +443,10 @@ class TFBertSplited(PolusModel):
         self.run_in_training_mode = run_in_training_mode
         self.compute_dtype = arena.compute_dtype
         self._scratch = {}
+        self.dropout_base_seed, self.dropout_step = 4321, 0
 
     scratch = BertModel.scratch
+    site_seed = BertModel.site_seed
 
     @property
     def trainable_weights(self):
@@ -427,8 +458,13 @@ class TFBertSplited(PolusModel):
         B, S, H = hs.shape
         mask = to_device(attention_mask, torch.int32, dev)
         hidden = hs.reshape(B * S, H)
+        train = bool(self.run_in_training_mode and training)      # polus/models.py:213
+        p_hid = self.config.hidden_dropout_prob if train else 0.0
+        p_att = self.config.attention_probs_dropout_prob if train else 0.0
         for l in self.layer:
-            hidden = l.forward(hidden, mask, B, S)
+            hidden = l.forward(hidden, mask, B, S, p_hid, p_att, tuple(self.site_seed(l.index, k) for k in range(3)))
+        if train:
+            self.dropout_step += 1
         self._shape = (B, S)
         h3 = hidden.view(B, S, H)
         return BaseModelOutputWithPooling(last_hidden_state=h3, pooler_output=h3[:, 0, :])

@@ -56,7 +56,7 @@ def _req_cuda(*ts):
 
 
 def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=None, alpha=1.0,
-         bias=None, resid=None, aux=None, act=None, flags=0, split_k=1):
+         bias=None, resid=None, aux=None, act=None, flags=0, split_k=1, drop_p=0.0, seed=0):
     """out[M,N] = epilogue(alpha * A_op . B_op); see include/polus_hip.h polus_gemm."""
     lib = _lib.load()
     _req_cuda(a, b, out, bias, resid, aux)
@@ -85,13 +85,16 @@ def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=N
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.polus_gemm(dt, a_layout, b_layout, dtype_code(out.dtype),
-                         ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
-                         M, N, K, float(alpha), ptr(bias),
-                         ptr(resid), resid.stride(0) if resid is not None else 0,
-                         ptr(aux), aux.stride(0) if aux is not None else 0,
-                         ACT_CODES[act] if not isinstance(act, int) else act, flags, split_k,
-                         ptr(ws), ws_bytes, _st()), "polus_gemm")
+    common = (dt, a_layout, b_layout, dtype_code(out.dtype),
+              ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+              M, N, K, float(alpha), ptr(bias),
+              ptr(resid), resid.stride(0) if resid is not None else 0,
+              ptr(aux), aux.stride(0) if aux is not None else 0,
+              ACT_CODES[act] if not isinstance(act, int) else act, flags, split_k, ptr(ws), ws_bytes)
+    if drop_p > 0.0:
+        check(lib.polus_gemm_dropout(*common, float(drop_p), int(seed) & 0xFFFFFFFF, _st()), "polus_gemm_dropout")
+    else:
+        check(lib.polus_gemm(*common, _st()), "polus_gemm")
     if prof is not None:
         e1.record()
         kind = "fwd" if (a_layout == K_CONTIG and b_layout == K_CONTIG) else ("dx" if a_layout == K_CONTIG else "dw")
@@ -99,7 +102,7 @@ def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=N
     return out
 
 
-def attention_fwd(qkv, mask, ctx, lse, B, S, n_heads):
+def attention_fwd(qkv, mask, ctx, lse, B, S, n_heads, drop_p=0.0, seed=0):
     lib = _lib.load()
     _req_cuda(qkv, mask, ctx, lse)
     H = n_heads * 64
@@ -107,10 +110,10 @@ def attention_fwd(qkv, mask, ctx, lse, B, S, n_heads):
     assert lse.dtype == torch.float32 and lse.numel() == B * n_heads * S
     assert mask is None or (mask.dtype == torch.int32 and mask.numel() == B * S and mask.is_contiguous())
     check(lib.polus_attention_fwd(dtype_code(qkv.dtype), ptr(qkv), ptr(mask), ptr(ctx), ptr(lse),
-                                  B, S, n_heads, 64, _st()), "polus_attention_fwd")
+                                  B, S, n_heads, 64, float(drop_p), int(seed) & 0xFFFFFFFF, _st()), "polus_attention_fwd")
 
 
-def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, n_heads):
+def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, n_heads, drop_p=0.0, seed=0):
     lib = _lib.load()
     _req_cuda(qkv, mask, ctx, dctx, lse, dqkv)
     H = n_heads * 64
@@ -119,7 +122,8 @@ def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, n_heads):
     nb = lib.polus_attention_bwd_workspace_bytes(B, S, n_heads)
     ws = workspace(qkv.device).get(nb)
     check(lib.polus_attention_bwd(dtype_code(qkv.dtype), ptr(qkv), ptr(mask), ptr(ctx), ptr(dctx), ptr(lse),
-                                  ptr(dqkv), B, S, n_heads, 64, ptr(ws), nb, _st()), "polus_attention_bwd")
+                                  ptr(dqkv), B, S, n_heads, 64, float(drop_p), int(seed) & 0xFFFFFFFF, ptr(ws), nb, _st()),
+          "polus_attention_bwd")
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
@@ -131,7 +135,8 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
                                   rows, H, float(eps), _st()), "polus_layernorm_fwd")
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias=None, accumulate=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias=None, accumulate=False, dx_masked=None,
+                  drop_p=0.0, seed=0):
     lib = _lib.load()
     _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias)
     rows, H = x.shape
@@ -140,10 +145,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias=None, accum
     ws = workspace(x.device).get(nb)
     check(lib.polus_layernorm_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
                                   ptr(dgamma), ptr(dbeta), ptr(dbias), int(accumulate), rows, H,
-                                  ptr(ws), nb, _st()), "polus_layernorm_bwd")
+                                  ptr(dx_masked), float(drop_p), int(seed) & 0xFFFFFFFF, ptr(ws), nb, _st()), "polus_layernorm_bwd")
 
 
-def embed_ln_fwd(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd, eps):
+def embed_ln_fwd(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd, eps, drop_p=0.0, seed=0):
     lib = _lib.load()
     _req_cuda(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd)
     B, S = ids.shape
@@ -152,11 +157,12 @@ def embed_ln_fwd(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd, eps)
     assert type_ids is None or (type_ids.dtype == torch.int32 and type_ids.is_contiguous())
     check(lib.polus_embed_ln_fwd(dtype_code(y.dtype), ptr(ids), ptr(type_ids), ptr(word), ptr(pos), ptr(typ),
                                  ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
-                                 B, S, H, V, pos.shape[0], typ.shape[0], float(eps), _st()), "polus_embed_ln_fwd")
+                                 B, S, H, V, pos.shape[0], typ.shape[0], float(eps), float(drop_p), int(seed) & 0xFFFFFFFF,
+                                 _st()), "polus_embed_ln_fwd")
 
 
 def embed_ln_bwd(dy, ids, type_ids, word, pos, typ, gamma, mean, rstd, gword, gpos, gtyp, ggamma, gbeta,
-                 accumulate=False, deterministic=False):
+                 accumulate=False, deterministic=False, drop_p=0.0, seed=0):
     lib = _lib.load()
     _req_cuda(dy, ids, word, gword)
     B, S = ids.shape
@@ -166,7 +172,8 @@ def embed_ln_bwd(dy, ids, type_ids, word, pos, typ, gamma, mean, rstd, gword, gp
     check(lib.polus_embed_ln_bwd(dtype_code(dy.dtype), ptr(dy), ptr(ids), ptr(type_ids), ptr(word), ptr(pos), ptr(typ),
                                  ptr(gamma), ptr(mean), ptr(rstd), ptr(gword), ptr(gpos), ptr(gtyp), ptr(ggamma),
                                  ptr(gbeta), int(accumulate), int(deterministic),
-                                 B, S, H, V, pos.shape[0], typ.shape[0], ptr(ws), nb, _st()), "polus_embed_ln_bwd")
+                                 B, S, H, V, pos.shape[0], typ.shape[0], float(drop_p), int(seed) & 0xFFFFFFFF,
+                                 ptr(ws), nb, _st()), "polus_embed_ln_bwd")
 
 
 def colsum(x, out, accumulate=False, rows=None, cols=None):
@@ -302,3 +309,17 @@ def dense_bwd_params(dy, x, dw, db, accumulate=False, split_k=1):
     if prof is not None:
         e1.record()
         prof.append(("dw", 2.0 * T * n_out * n_in, e0, e1))
+
+
+def dropout(x, y, drop_p, seed):
+    _req_cuda(x, y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(_lib.load().polus_dropout(dtype_code(x.dtype), ptr(x), ptr(y), x.numel(), float(drop_p), int(seed) & 0xFFFFFFFF, _st()),
+          "polus_dropout")
+
+
+def dropout_mask(seed, drop_p, n, idx0=0, device=None):
+    """uint8 keep-mask of elements idx0..idx0+n-1 for `seed` (reference for every dropout site)."""
+    m = torch.empty(int(n), dtype=torch.uint8, device=device or "cuda")
+    check(_lib.load().polus_dropout_mask(int(seed) & 0xFFFFFFFF, float(drop_p), int(idx0), int(n), ptr(m), _st()), "polus_dropout_mask")
+    return m

@@ -293,3 +293,85 @@ def test_bert_large_shapes_one_layer():
     og = ob.token_classifier_bwd(params, ocfg, hw, cache)
     for v in model.trainable_weights:
         assert_close(host(v.grad), og[v.name], 2e-4, v.name)
+
+
+def _oracle_drop(model, ocfg, B, S, p_hid, p_att, step):
+    """Keep-scales of every dropout site of training step `step`, regenerated on the GPU with the
+    same (seed, index) hash the fused kernels use."""
+    from polus_amd import ops
+    H, A, L = ocfg.hidden_size, ocfg.num_attention_heads, ocfg.num_hidden_layers
+    ks = lambda seed, p, shape: ops.dropout_mask(seed, p, int(np.prod(shape))).cpu().numpy().reshape(shape).astype(np.float64) / (1.0 - p)
+    drop = {"emb": ks(model.site_seed(-1, 0, step), p_hid, (B, S, H)), "layers": []}
+    for l in range(L):
+        drop["layers"].append({"att": ks(model.site_seed(l, 0, step), p_att, (B, A, S, S)),
+                               "h1": ks(model.site_seed(l, 1, step), p_hid, (B, S, H)),
+                               "h2": ks(model.site_seed(l, 2, step), p_hid, (B, S, H))})
+    return drop
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_dropout_matches_oracle_with_regenerated_masks(mode):
+    """HF BERT dropout sites (embeddings, attention probabilities, both Dense outputs before the
+    residual) with p = 0.1/0.15: forward loss/logits and every gradient vs the oracle run with the
+    exact masks; masks are fresh each step and absent in inference."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import BertConfig, BertModel
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b3_s48")
+    p_hid, p_att = 0.1, 0.15
+    cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                     ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size,
+                     hidden_dropout_prob=p_hid, attention_probs_dropout_prob=p_att)
+    model = BertModel(cfg, compute_dtype=mode, num_labels=4)
+    model.load_numpy_params(params, head_w, head_b)
+    loss_fn = SparseCategoricalCrossentropy(grad_dtype=model.compute_dtype)
+    x = {"input_ids": g["ids"], "attention_mask": g["mask"], "token_type_ids": g["token_type"]}
+    B, S = g["ids"].shape
+    # inference: no dropout -> the golden logits
+    assert_close(host(model(**x, training=False)), g["logits"], TOLS[mode]["logits"], "inference logits")
+    losses = []
+    for step in range(2):
+        logits = model(**x, training=True)
+        loss = float(loss_fn(g["labels"], logits))
+        model.backward(loss_fn.backward())
+        drop = _oracle_drop(model, ocfg, B, S, p_hid, p_att, step)
+        ref_loss, ref_logits, cache = ob.token_classifier_fwd(params, ocfg, head_w, head_b, g["ids"], g["mask"], g["labels"],
+                                                              g["token_type"], drop)
+        og = ob.token_classifier_bwd(params, ocfg, head_w, cache)
+        tol = TOLS[mode]
+        assert abs(loss - ref_loss) < tol["loss"] * 2, (step, loss, ref_loss)
+        assert_close(host(logits), ref_logits, tol["logits"] * 2, f"dropout logits step {step}")
+        for v in model.trainable_weights:
+            assert_close(host(v.grad), og[v.name], tol["grad"] * 2, f"dropout grad {v.name} step {step}")
+        losses.append(loss)
+        keep = drop["layers"][0]["h1"] > 0
+        assert abs(keep.mean() - (1 - p_hid)) < 0.02 and abs((drop["layers"][0]["att"] > 0).mean() - (1 - p_att)) < 0.02
+    assert losses[0] != losses[1]          # fresh masks every step
+    assert abs(losses[0] - float(g["loss"])) > 1e-4   # and they do change the loss
+
+
+def test_dropout_layer_and_gemm_mask_consistency():
+    from polus_amd import ops
+    from polus_amd.layers import Dropout
+    x = torch.randn(64, 96, device="cuda")
+    d = Dropout(0.25)
+    assert d.forward(x, training=False) is x
+    y = d.forward(x, training=True)
+    kept = (y != 0)
+    assert abs(kept.float().mean().item() - 0.75) < 0.03
+    assert torch.allclose(y[kept], x[kept] / 0.75)
+    dy = torch.randn_like(x)
+    dx = d.backward(dy)
+    assert torch.equal(dx != 0, kept) and torch.allclose(dx[kept], dy[kept] / 0.75)
+    y2 = d.forward(x, training=True)
+    assert not torch.equal(y2 != 0, kept)                     # new mask next call
+    # GEMM epilogue dropout == mask from the reference kernel (ring kernel and 128x128 kernel)
+    for (M, N, K) in [(512, 256, 64), (100, 72, 40)]:
+        a, b = torch.randn(M, K, device="cuda").bfloat16(), torch.randn(N, K, device="cuda").bfloat16()
+        r = torch.randn(M, N, device="cuda").bfloat16()
+        plain = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        drop = torch.empty_like(plain)
+        ops.gemm(a, b, plain)
+        ops.gemm(a, b, drop, resid=r, drop_p=0.3, seed=1234)
+        m = ops.dropout_mask(1234, 0.3, M * N).view(M, N).bool()
+        ref = torch.where(m, plain.float() / 0.7, torch.zeros_like(plain.float())) + r.float()
+        assert_close(host(drop), ref.cpu().numpy(), 1e-2, f"gemm dropout {M}x{N}")
