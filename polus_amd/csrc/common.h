@@ -126,6 +126,11 @@ __device__ __forceinline__ uint32_t polus_hash32(uint32_t seed, uint32_t idx) {
 __device__ __forceinline__ bool polus_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
     return polus_hash32(seed, idx) >= thresh;
 }
+// two masks per hash (16-bit halves; thresh16 = thresh >> 16): halves the ALU work of the fused
+// epilogues.  Element idx uses half (idx & 1) of hash(seed, idx >> 1).
+__device__ __forceinline__ bool polus_keep16(uint32_t h, int half, uint32_t thresh) {
+    return ((half ? (h >> 16) : (h & 0xFFFFu)) >= (thresh >> 16));
+}
 static inline uint32_t polus_drop_thresh(float p) {
     double t = (double)p * 4294967296.0;
     return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);

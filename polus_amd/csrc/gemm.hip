@@ -136,7 +136,7 @@ __device__ __forceinline__ void frag_ks(Frag<float>& f, const unsigned char* til
         f.v[j] = *reinterpret_cast<const float*>(tile + (8 * g + j) * 512 + cb);
 }
 
-template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC>
+template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC, bool DROP>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = Cfg<T>::BK, NSUB = Cfg<T>::NSUB;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
-            epilogue_tile<T, TC>(p, acc[tm][tn], m0 + wm * 64 + tm * 16 + i, n0 + wn * 64 + tn * 16 + 4 * g, blockIdx.z);
+            epilogue_tile<T, TC, DROP>(p, acc[tm][tn], m0 + wm * 64 + tm * 16 + i, n0 + wn * 64 + tn * 16 + 4 * g, blockIdx.z);
 }
 
 // order-fixed split-K reduction: C = alpha * sum_z slab[z] (+ bias) (+ C)
@@ -226,10 +226,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     *c = from_f<TC>(s);
 }
 
-template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC>
+template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC, bool DROP = false>
 int launch_v(const GemmArgs& a, dim3 grid, hipStream_t st) {
     static bool attr_done = false;  // per instantiation
-    auto kern = gemm_kernel<T, A_KS, B_KS, TC, VEC>;
+    auto kern = gemm_kernel<T, A_KS, B_KS, TC, VEC, DROP>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
@@ -355,6 +355,17 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.c_split_stride = 0;
     a.colsum_a = nullptr;
     const bool both_kc = a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG;
+    if (flags & POLUS_GEMM_DROPOUT) {
+        // forward Dense only: K-contiguous operands, C in the compute dtype
+        POLUS_REQUIRE(both_kc && c_dtype == dtype, "polus_gemm_dropout: needs K-contiguous operands and c_dtype == dtype");
+        if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
+            a.k_per_split = ((K + 31) / 32) * 32;
+            return polus_launch_gemm_ring_dropout(a, st);
+        }
+        const bool v = a.a_vec && a.b_vec;
+        if (dtype == POLUS_BF16) return v ? launch_v<bf16_t, false, false, bf16_t, true, true>(a, grid, st) : launch_v<bf16_t, false, false, bf16_t, false, true>(a, grid, st);
+        return v ? launch_v<float, false, false, float, true, true>(a, grid, st) : launch_v<float, false, false, float, false, true>(a, grid, st);
+    }
     const int a_ks = a_layout == POLUS_K_STRIDED, b_ks = b_layout == POLUS_K_STRIDED;
     if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
         if (split_k <= 1) {

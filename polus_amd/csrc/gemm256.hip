@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
     // every wave is done with the operand stages (and no DMA is in flight): reuse LDS for the C staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    epilogue_wave_128x64_lds<TC, false>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
 template <typename TC>

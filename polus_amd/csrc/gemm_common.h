@@ -44,7 +44,7 @@ template <typename TC> __device__ __forceinline__ void st4x(TC* p, const float (
 // Epilogue for one 16x16 accumulator tile issued as D[n][m]: the lane holds C[m][n..n+3]
 // (m = tile row lane&15, n = 4*(lane>>4) + r).  Order: alpha, bias, ACT_FWD (aux = pre-activation),
 // ACT_BWD (* act'(aux)), residual, ACCUM_C.
-template <typename T, typename TC>
+template <typename T, typename TC, bool DROP = false>
 __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4& acc, int m, int n, int split) {
     if (m >= p.M) return;
     const int nvalid = p.N - n;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4& ac
         float u[4]; ld4x<T>(static_cast<const T*>(p.aux) + (long)m * p.ldaux + n, u, ev, nvalid);
         apply_act_grad_n<4>(p.act, v, u);
     }
-    if (p.flags & POLUS_GEMM_DROPOUT) {
+    if (DROP) {
         const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = polus_keep(p.drop_seed, base + r, p.drop_thresh) ? v[r] * p.drop_inv : 0.0f;
@@ -98,18 +98,18 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 // wave-private 32-row x 64-column f32 buffer (272-byte rows: conflict-free b128 writes).  LDS
 // operations of one wave execute in order, so no barrier is involved.  `lds` must point to
 // 8704 bytes owned by this wave; the caller guarantees nobody still reads operand tiles there.
-template <typename TC>
+template <typename TC, bool DROP = false>
 __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x4 (&acc)[8][4], int mb, int nb,
                                                          int lane, unsigned char* lds) {
     typedef bf16_t T;
     const int i = lane & 15, g = lane >> 4;
     const bool interior = p.epi_vec16 && !p.partial && (mb + 128 <= p.M) && (nb + 64 <= p.N);
     if (!interior) {
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int nt = 0; nt < 4; ++nt)
-                epilogue_tile<T, TC>(p, acc[mt][nt], mb + mt * 16 + i, nb + nt * 16 + 4 * g, 0);
+                epilogue_tile<T, TC, DROP>(p, acc[mt][nt], mb + mt * 16 + i, nb + nt * 16 + 4 * g, 0);
         return;
     }
     constexpr int RS = 272;
@@ -126,14 +126,14 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
     const T* resid = static_cast<const T*>(p.resid);
     T* aux = static_cast<T*>(p.aux);
     TC* C = static_cast<TC*>(p.C);
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
                 *reinterpret_cast<f32x4*>(lds + (a * 16 + i) * RS + (nt * 16 + 4 * g) * 4) = acc[2 * c + a][nt];
-#pragma unroll
+#pragma clang loop unroll(full)
       for (int ph = 0; ph < 4; ph += 1) {
         bf16x8_t rr[1], uu[1];
         float oo[1][8];
@@ -178,7 +178,7 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
                 for (int r = 0; r < 8; ++r) u[r] = (float)uu[ps][r];
                 apply_act_grad_n<8>(p.act, v, u);
             }
-            if (p.flags & POLUS_GEMM_DROPOUT) {
+            if (DROP) {
                 const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = polus_keep(p.drop_seed, base + r, p.drop_thresh) ? v[r] * p.drop_inv : 0.0f;
@@ -220,3 +220,5 @@ int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st)
 // gemm_ring.hip: same contract, 256x128 tile, two workgroups per CU.
 // a_ks / b_ks: operand stored [K][rows]; splits > 1: blockIdx.y selects [y*k_per_split, ..) and C + y*c_split_stride.
 int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st);
+// dropout epilogue (POLUS_GEMM_DROPOUT): bf16 C, both operands K-contiguous only.
+int polus_launch_gemm_ring_dropout(const pgemm::GemmArgs& a, hipStream_t st);

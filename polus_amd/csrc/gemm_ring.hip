@@ -47,7 +47,7 @@ __device__ __forceinline__ int pi4(int q) { return (0x78 >> (2 * q)) & 3; }
 #define POLUS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define POLUS_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <typename TC, bool A_KS, bool B_KS>
+template <typename TC, bool A_KS, bool B_KS, bool DROP>
 __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -213,13 +213,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
         }
     }
     p.C = static_cast<TC*>(p.C) + (long)blockIdx.y * p.c_split_stride;
-    epilogue_wave_128x64_lds<TC>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    epilogue_wave_128x64_lds<TC, DROP>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
-template <typename TC, bool A_KS, bool B_KS>
+template <typename TC, bool A_KS, bool B_KS, bool DROP = false>
 int launch_ring(const GemmArgs& a, int splits, hipStream_t st) {
     static bool attr_done = false;
-    auto kern = gemm_ring_kernel<TC, A_KS, B_KS>;
+    auto kern = gemm_ring_kernel<TC, A_KS, B_KS, DROP>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
@@ -240,6 +240,10 @@ int launch_layout(const GemmArgs& a, int a_ks, int b_ks, int splits, hipStream_t
 }
 
 }  // namespace
+
+int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
+    return launch_ring<bf16_t, false, false, true>(a, 1, st);
+}
 
 int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st) {
     return c_is_f32 ? launch_layout<float>(a, a_ks, b_ks, splits, st) : launch_layout<bf16_t>(a, a_ks, b_ks, splits, st);
