@@ -47,8 +47,11 @@ def test_argument_validation_happens_on_the_host(lib):
     # bad shapes are rejected before any launch, with a message
     rc = lib.polus_gemm(0, 0, 0, 0, None, 8, None, 8, None, 8, 8, 8, 8, 1.0, None, None, 0, None, 0, 0, 0, 1, None, 0, None)
     assert rc != 0 and b"null operand" in lib.polus_last_error()
-    rc = lib.polus_attention_fwd(0, ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 8, 2, 32, None)
+    rc = lib.polus_attention_fwd(0, ctypes.c_void_p(16), None, ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 8, 2, 32, 0.0, 0, None)
     assert rc != 0 and b"head_dim" in lib.polus_last_error()
+    rc = lib.polus_gemm_dropout(1, 0, 0, 1, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 8, 8, 8, 8, 1.0,
+                                None, None, 0, None, 0, 0, 0, 1, None, 0, 1.5, 7, None)
+    assert rc != 0 and b"0 <= p < 1" in lib.polus_last_error()
 
 
 def test_no_cpu_fallback():
