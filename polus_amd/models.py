@@ -129,9 +129,12 @@ class BertLayer:
         self._stash = (x, mask, B, S, p_hid, p_att, seeds)
         return y
 
-    def backward(self, dy, scratch, accumulate=False):
+    def backward(self, dy, scratch, accumulate=False, side=None):
         """dy [T,H] -> dx [T,H]; parameter gradients land in the arena (overwritten, or added
-        to when `accumulate`).  `scratch(key, shape)` hands out buffers shared by all layers."""
+        to when `accumulate`).  `scratch(key, shape)` hands out buffers shared by all layers.
+        `side`: a second HIP stream for the four dW GEMMs.  They only depend on tensors that are
+        written once per layer, so they run beside the dX GEMM / LayerNorm / attention-backward
+        chain and fill the CUs those leave idle; the layer joins the two streams before returning."""
         cfg = self.cfg
         H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         x, mask, B, S, p_hid, p_att, seeds = self._stash
@@ -143,26 +146,45 @@ class BertLayer:
         da1, dz1 = scratch("da1", (T, H)), scratch("dz1", (T, H))
         dctx, dqkv = scratch("dctx", (T, H)), scratch("dqkv", (T, 3 * H))
         dx = scratch("dx%d" % (self.index & 1), (T, H))
+        main = torch.cuda.current_stream()
+        if side is not None and not hasattr(self, "_ev"):
+            self._ev = [torch.cuda.Event() for _ in range(5)]
+
+        def on_side(k, fn):
+            """Run fn on the side stream once everything queued so far on the main stream is done."""
+            if side is None:
+                return fn()
+            self._ev[k].record(main)
+            side.wait_event(self._ev[k])
+            with torch.cuda.stream(side):
+                fn()
         # z2 = dropout(ffn2(f)) + a1: the residual path takes dz2, the Dense path dz2 * mask/(1-p)
         dz2m = scratch("dz2m", (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(dy, bb["z2"], self.ln2_g.value, bb["m2"], bb["r2"], dz2,
                           self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate,
                           dx_masked=dz2m, drop_p=p_hid, seed=seeds[2])
         dz2d = dz2m if dz2m is not None else dz2
-        ops.gemm(dz2d, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, I, T))
+        on_side(0, lambda: ops.gemm(dz2d, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc,
+                                    split_k=dw_split_k(H, I, T)))
         gemm_dx(dz2d, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
-        ops.dense_bwd_params(du, bb["a1"], self.ffn1_w.grad, self.ffn1_b.grad, accumulate, dw_split_k(I, H, T))
+        on_side(1, lambda: ops.dense_bwd_params(du, bb["a1"], self.ffn1_w.grad, self.ffn1_b.grad, accumulate,
+                                                dw_split_k(I, H, T)))
         gemm_dx(du, self.ffn1_w, da1, resid=dz2)
         dz1m = scratch("dz1m", (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(da1, bb["z1"], self.ln1_g.value, bb["m1"], bb["r1"], dz1,
                           self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate,
                           dx_masked=dz1m, drop_p=p_hid, seed=seeds[1])
         dz1d = dz1m if dz1m is not None else dz1
-        ops.gemm(dz1d, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc, split_k=dw_split_k(H, H, T))
+        on_side(2, lambda: ops.gemm(dz1d, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc,
+                                    split_k=dw_split_k(H, H, T)))
         gemm_dx(dz1d, self.out_w, dctx)
         ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A, drop_p=p_att, seed=seeds[0])
-        ops.dense_bwd_params(dqkv, x, self.qkv_w.grad, self.qkv_b.grad, accumulate, dw_split_k(3 * H, H, T))
+        on_side(3, lambda: ops.dense_bwd_params(dqkv, x, self.qkv_w.grad, self.qkv_b.grad, accumulate,
+                                                dw_split_k(3 * H, H, T)))
         gemm_dx(dqkv, self.qkv_w, dx, resid=dz1)
+        if side is not None:     # join: the next layer reuses dz2/du/dz1/dqkv, and the reducer may read the grads
+            self._ev[4].record(side)
+            main.wait_event(self._ev[4])
         return dx
 
 
@@ -348,6 +370,8 @@ class BertModel(PolusModel):
         self._scratch = {}
         self.dropout_base_seed = seed
         self.dropout_step = 0     # advanced once per training forward: fresh masks every step
+        self.overlap_dw = os.environ.get("POLUS_OVERLAP_DW", "1") != "0"
+        self._side = None
 
     def scratch(self, key, shape):
         t = self._scratch.get(key)
@@ -413,8 +437,10 @@ class BertModel(PolusModel):
             self._notify(self.head.variables())
         else:
             dy = to_device(dy, self.compute_dtype, self.arena.device).reshape(B * S, -1)
+        if self.overlap_dw and self._side is None:
+            self._side = torch.cuda.Stream(device=self.arena.device)
         for l in reversed(self.layer):
-            dy = l.backward(dy, self.scratch, accumulate)
+            dy = l.backward(dy, self.scratch, accumulate, self._side if self.overlap_dw else None)
             self._notify(l.variables())
         if self.embeddings is not None:
             self.embeddings.backward(dy, accumulate, self.deterministic)

@@ -375,3 +375,49 @@ def test_dropout_layer_and_gemm_mask_consistency():
         m = ops.dropout_mask(1234, 0.3, M * N).view(M, N).bool()
         ref = torch.where(m, plain.float() / 0.7, torch.zeros_like(plain.float())) + r.float()
         assert_close(host(drop), ref.cpu().numpy(), 1e-2, f"gemm dropout {M}x{N}")
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-3), ("bf16", 5e-2)])
+def test_loss_trajectory_100_steps(mode, tol):
+    """BASELINE.md target: loss within 1e-3 of the reference math at step 100 (f32 engine, dropout 0,
+    deterministic reductions).  100 AdamW steps with the warm-up schedule through ClassifierTrainer vs
+    the NumPy oracle trained in float64 on the same batches."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.schedulers import warmup_scheduler
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b2_s16")
+    steps = 100
+    model = build_model(ocfg, params, head_w, head_b, mode)
+    model.deterministic = True
+    trainer = ClassifierTrainer(model, AdamWeightDecay(learning_rate=warmup_scheduler(steps, 5e-4), weight_decay_rate=0.01),
+                                SparseCategoricalCrossentropy(grad_dtype=model.compute_dtype))
+    allp = dict(params); allp["head.w"] = head_w.copy(); allp["head.b"] = head_b.copy()
+    allp = {k: v.copy() for k, v in allp.items()}
+    opt = oo.Adam(lr=lambda t: oo.warmup_linear_lr(t, steps, 5e-4), weight_decay=0.01,
+                  no_decay=[k for k in allp if oo.is_no_decay(k)])
+    worst = 0.0
+    for s in range(steps):
+        ids, mask, tt, labels = synth_batch(ocfg, 2, 16, 4, 900 + s % 7)     # 7 recurring batches: the loss really falls
+        loss = float(trainer.train_step({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels))
+        ref, _, cache = ob.token_classifier_fwd(allp, ocfg, allp["head.w"], allp["head.b"], ids, mask, labels, tt)
+        opt.step(allp, ob.token_classifier_bwd(allp, ocfg, allp["head.w"], cache))
+        worst = max(worst, abs(loss - ref))
+    assert ref < 1.2, "the model should have learned something in 100 steps"
+    assert abs(loss - ref) < tol and worst < tol * 2, (loss, ref, worst)
+
+
+def test_save_and_reload_weights(tmp_path):
+    from polus_amd.checkpoint import load_weights
+    from polus_amd.layers import Dense, Flatten
+    from polus_amd.models import SequentialPolusClassifier
+    mk = lambda: SequentialPolusClassifier([Flatten(input_shape=(4, 4)), Dense(8, activation="relu"), Dense(3)],
+                                           compute_dtype="f32", input_dim=16, name="clf")
+    a, b = mk(), mk()
+    a.trainable_weights[0].assign(np.random.default_rng(1).standard_normal((8, 16)).astype(np.float32))
+    path = a.save(base_path=str(tmp_path), extension="_e0")
+    assert os.path.exists(path + ".cfg") and os.path.exists(path + ".npz")
+    load_weights(b, path)
+    x = np.random.default_rng(2).standard_normal((5, 4, 4)).astype(np.float32)
+    assert torch.equal(a(x), b(x))
