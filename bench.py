@@ -178,9 +178,15 @@ def main():
             peak = PEAK_TFLOPS[args.dtype]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
-                    "kernel": f"gemm_kernel<{args.dtype}, K-contig x K-contig> (forward Dense: QKV, out, FFN1, FFN2)",
+                    "kernel": ("gemm_ring_kernel<bf16, A K-contig, B K-contig>" if args.dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig>")
+                              + " (forward Dense: QKV, out-proj, FFN1, FFN2; with and without the dropout epilogue)",
                     "launches": len(fwd), "avg_launch_us": round(tsum / len(fwd) * 1e6, 2),
                     "flops_per_launch": fsum / len(fwd)}
+            tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+            if args.dtype == "bf16" and os.path.exists(tf) and (B, S, L, H) == (64, 256, 12, 768):
+                # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (FETCH_SIZE x2
+                # gfx950 correction, WRITE_SIZE), see profiles/README.md
+                roof["traffic"] = json.load(open(tf))["bytes_per_launch"]
             allg = [(e0.elapsed_time(e1) * 1e-3, fl) for (_, fl, e0, e1) in rec]
             roof["all_gemm_tflops"] = round(sum(f for _, f in allg) / sum(t for t, _ in allg) / 1e12, 2)
             roof["all_gemm_ms_per_step"] = round(sum(t for t, _ in allg) * 1e3, 3)
