@@ -164,13 +164,15 @@ def main():
         elapsed = float(t.item())
 
     # ---- instrumented step: HIP events around every launch of the dominant kernel
+    # (every rank takes the step -- it contains the gradient all-reduce -- only rank 0 records)
     roof = None
+    rec = []
     if rank == 0:
-        rec = []
         ops.GEMM_PROFILE = rec
-        one_step(args.warmup + args.steps)
-        torch.cuda.synchronize()
-        ops.GEMM_PROFILE = None
+    one_step(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    ops.GEMM_PROFILE = None
+    if rank == 0:
         fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for (key, fl, e0, e1) in rec if key == "fwd"]
         if fwd:
             tsum, fsum = sum(t for t, _ in fwd), sum(f for _, f in fwd)

@@ -39,14 +39,15 @@ def init():
         return "mock"
     rank, local_rank = _env_int("RANK", 0), _env_int("LOCAL_RANK", 0)
     use_gpu = torch.cuda.is_available()
-    backend = "nccl" if use_gpu else "gloo"
+    # POLUS_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices)
+    backend = os.environ.get("POLUS_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if use_gpu:
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
-        if use_gpu:
+        if use_gpu and backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     _STATE.update(world=dist.get_world_size(), rank=dist.get_rank(), local_rank=local_rank, backend=backend)

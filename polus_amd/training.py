@@ -78,7 +78,7 @@ class BaseTrainer:
     def _reducer(self, arena):
         r = self._reducers.get(id(arena))
         if r is None:
-            bucket = int(os.environ.get("POLUS_BUCKET_MB", "64")) << 20
+            bucket = int(float(os.environ.get("POLUS_BUCKET_MB", "64")) * (1 << 20))
             r = comm.GradBucketReducer(arena.grads, bucket_bytes=bucket,
                                        boundaries=[v.offset for v in arena.vars])
             self._reducers[id(arena)] = r

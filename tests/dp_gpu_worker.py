@@ -1,0 +1,54 @@
+"""Worker of tests/test_dp_gpu.py: one rank of a 2-rank data-parallel job whose ranks share
+the box's single MI355X (gloo transport: RCCL refuses two ranks on one device).  Everything
+but the wire -- kernels, arenas, bucket reducer, Adam's folded 1/N, LR x world, the step-0
+broadcast -- is the product path."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out = sys.argv[1]
+    from polus_amd import comm
+    from polus_amd.context import PolusContext
+    from polus_amd.data import shard
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.schedulers import warmup_scheduler
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    from tests.test_model_gpu import build_model, load_case
+
+    ctx = PolusContext()
+    assert ctx.is_horovod_enabled() and comm.size() == 2
+    rank = comm.rank()
+    g, ocfg, params, head_w, head_b = load_case("bert_small_b2_s16")
+    if rank == 1:     # rank 1 starts from different weights: the step-0 broadcast must fix that
+        params = {k: v + 0.01 for k, v in params.items()}
+    model = build_model(ocfg, params, head_w, head_b, "f32")
+    steps = 3
+    opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps, 1e-3), weight_decay_rate=0.01)
+    trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
+    assert trainer.use_horovod
+    os.environ["POLUS_BUCKET_MB"] = "0.05"        # several buckets even for this small model
+    mine = list(shard(range(4), 2, rank))                  # sample i -> rank i mod 2
+    batches = []
+    for s in range(steps):
+        ids, mask, tt, labels = synth_batch(ocfg, 4, 16, 4, 420 + s)
+        batches.append(({"input_ids": ids[mine], "attention_mask": mask[mine], "token_type_ids": tt[mine]},
+                        labels[mine]))
+    trainer.train(batches, epochs=1, callbacks=[])
+    # the parent compares parameters, which depend on every step's averaged gradients
+    flat = model.arena.params.detach().float().cpu().numpy()
+    np.save(f"{out}.rank{rank}.npy", flat)
+    comm.barrier()
+    comm.shutdown()
+    print(f"rank {rank} OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()
