@@ -78,10 +78,47 @@ __device__ __forceinline__ float swish_grad_f(float x) {
     float s = 1.0f / (1.0f + __expf(-x));
     return s * (1.0f + x * (1.0f - s));
 }
+// bf16 engine: GELU and its derivative without transcendentals.  Phi(x) = 0.5 + x q(u) and
+// gelu'(x) = Phi(x) + x phi(x) = 0.5 + x w(u) with u = 2 x^2 / c^2 - 1 on |x| <= c = 4.5 (clamped
+// outside: Phi(4.5) = 1 - 3.4e-6), q and w degree-10 minimax fits evaluated by Horner on pairs
+// (v_pk_fma_f32).  |gelu error| <= 2e-5, |gelu' error| <= 1e-4 -- far below a bf16 ulp of the
+// outputs they feed; the erf/exp forms above cost ~3x as many VALU cycles, and epilogue VALU time is
+// not hidden behind the matrix pipe.  The f32 engine keeps erf_fast.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_poly2(f32x2_t x, const float (&c)[11]) {
+    f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+    f32x2_t s = xc * xc;
+    f32x2_t u = __builtin_elementwise_fma(s, (f32x2_t){2.0f / 20.25f, 2.0f / 20.25f}, (f32x2_t){-1.0f, -1.0f});
+    f32x2_t r = {c[10], c[10]};
+#pragma unroll
+    for (int k = 9; k >= 0; --k) r = __builtin_elementwise_fma(r, u, (f32x2_t){c[k], c[k]});
+    return __builtin_elementwise_fma(xc, r, (f32x2_t){0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x2_t gelu_cdf2(f32x2_t x) {
+    const float q[11] = {1.569049305e-01f, -7.719386095e-02f, 5.470119065e-02f, -4.010921159e-02f, 2.828393083e-02f,
+                         -1.902094059e-02f, 1.143922652e-02f, -5.251548121e-03f, 2.716277400e-03f, -2.340015935e-03f,
+                         9.806926012e-04f};
+    return gelu_poly2(x, q);
+}
+__device__ __forceinline__ f32x2_t gelu_grad2(f32x2_t x) {
+    const float w[11] = {1.594289755e-01f, -9.003904569e-02f, 8.714168751e-02f, -9.350841452e-02f, 9.645831298e-02f,
+                         -9.557466143e-02f, 7.437658385e-02f, -3.356380937e-02f, 2.252388123e-02f, -3.068672777e-02f,
+                         1.457471506e-02f};
+    return gelu_poly2(x, w);
+}
 // `act` is wave-uniform (a kernel argument): real branches, so only one activation is evaluated
 // (nested selects would compute erf, exp and tanh for every element).
-template <int N> __device__ __forceinline__ void apply_act_n(int act, float (&v)[N]) {
+template <int N, bool FAST = false> __device__ __forceinline__ void apply_act_n(int act, float (&v)[N]) {
     if (act == POLUS_ACT_GELU) {
+        if (FAST && (N % 2) == 0) {
+#pragma unroll
+            for (int r = 0; r < N; r += 2) {
+                f32x2_t x = {v[r], v[r + 1]};
+                f32x2_t y = x * gelu_cdf2(x);
+                v[r] = y[0]; v[r + 1] = y[1];
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] = gelu_f(v[r]);
     } else if (act == POLUS_ACT_SWISH) {
@@ -96,8 +133,16 @@ template <int N> __device__ __forceinline__ void apply_act_n(int act, float (&v)
     }
 }
 // v[r] *= act'(u[r]) given the pre-activations u
-template <int N> __device__ __forceinline__ void apply_act_grad_n(int act, float (&v)[N], const float (&u)[N]) {
+template <int N, bool FAST = false> __device__ __forceinline__ void apply_act_grad_n(int act, float (&v)[N], const float (&u)[N]) {
     if (act == POLUS_ACT_GELU) {
+        if (FAST && (N % 2) == 0) {
+#pragma unroll
+            for (int r = 0; r < N; r += 2) {
+                f32x2_t d = (f32x2_t){v[r], v[r + 1]} * gelu_grad2((f32x2_t){u[r], u[r + 1]});
+                v[r] = d[0]; v[r + 1] = d[1];
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < N; ++r) v[r] *= gelu_grad_f(u[r]);
     } else if (act == POLUS_ACT_SWISH) {

@@ -261,6 +261,32 @@ extern "C" size_t polus_gemm_workspace_bytes(int M, int N, int split_k) {
     return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
 }
 
+static int polus_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+// The persistent 256x192 kernel (gemm_p.hip): higher FLOP per filled byte than the ring kernel, but
+// with one wave per SIMD nothing overlaps its epilogue, so it only wins where a tile has little to
+// write per FLOP (N <= K: attention-out and FFN2 forward, +9 %) and the epilogue has no second
+// store or load stream.  Needs K % 64 == 0, N % 192 == 0 and (nearly) full rounds of #CU tiles.
+static bool use_persistent(int M, int N, int K, int mode) {
+    // POLUS_GEMM_P: 0 = never, 1 = where it wins (default), 2 = whenever legal (tests)
+    const char* e = getenv("POLUS_GEMM_P");
+    const int sel = e ? atoi(e) : 1;
+    if (sel == 0 || mode < 0 || K % 64 != 0 || M < 256 || N < 192) return false;
+    if (sel == 2) return true;
+    if (!(mode == 0 || mode == 2) || N > K || (N % 192) != 0) return false;
+    const int ncu = polus_num_cus();
+    const long tiles = (long)((M + 255) / 256) * (N / 192);
+    const long rounds = (tiles + ncu - 1) / ncu;
+    return tiles * 100 >= rounds * ncu * 90;
+}
+
 static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
                      const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                      int M, int N, int K, float alpha,
@@ -360,6 +386,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
         POLUS_REQUIRE(both_kc && c_dtype == dtype, "polus_gemm_dropout: needs K-contiguous operands and c_dtype == dtype");
         if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
             a.k_per_split = ((K + 31) / 32) * 32;
+            if (use_persistent(M, N, K, polus_gemm_p_mode(a, 0, 1))) return polus_launch_gemm_p(a, polus_gemm_p_mode(a, 0, 1), 1, 192, polus_num_cus(), st);
             return polus_launch_gemm_ring_dropout(a, st);
         }
         const bool v = a.a_vec && a.b_vec;
@@ -372,6 +399,8 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
             // POLUS_GEMM_256=1 selects the one-workgroup-per-CU 256x256 kernel (kept for A/B runs)
             if (both_kc && getenv("POLUS_GEMM_256") && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
             a.k_per_split = ((K + 31) / 32) * 32;
+            if (both_kc && use_persistent(M, N, K, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0)))
+                return polus_launch_gemm_p(a, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), 0, 192, polus_num_cus(), st);
             return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, a_ks, b_ks, 1, st);
         }
         GemmArgs s = a;              // slabs: plain f32 stores, epilogue applied by the reduce kernel

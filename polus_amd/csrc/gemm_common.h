@@ -170,13 +170,13 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
                     for (int r = 0; r < 8; ++r) t[r] = (bf16_t)v[r];
                     *reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol) = t;
                 }
-                apply_act_n<8>(p.act, v);
+                apply_act_n<8, true>(p.act, v);
             }
             if (act_bwd) {
                 float u[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) u[r] = (float)uu[ps][r];
-                apply_act_grad_n<8>(p.act, v, u);
+                apply_act_grad_n<8, true>(p.act, v, u);
             }
             if (DROP) {
                 const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
@@ -222,3 +222,6 @@ int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st)
 int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st);
 // dropout epilogue (POLUS_GEMM_DROPOUT): bf16 C, both operands K-contiguous only.
 int polus_launch_gemm_ring_dropout(const pgemm::GemmArgs& a, hipStream_t st);
+// gemm_p.hip: persistent 256 x tn tile (tn = 192), one workgroup per CU, both operands K-contiguous, K % 64 == 0.
+int polus_gemm_p_mode(const pgemm::GemmArgs& a, int c_is_f32, int drop);   // -1: not built for this epilogue
+int polus_launch_gemm_p(const pgemm::GemmArgs& a, int mode, int drop, int tn, int ncu, hipStream_t st);

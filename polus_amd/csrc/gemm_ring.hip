@@ -67,6 +67,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
         const int wg = xcd_remap(blockIdx.x, gridDim.x);
         tile_m = wg / tiles_n; tile_n = wg % tiles_n;
     }
+    if ((p.ablate & 8) && blockIdx.x >= 256 && blockIdx.x < 512 && blockIdx.y == 0) {
+        // experiment: break the lock-step of the two workgroups of a CU (delay in units of ~3.4 us)
+        for (int d = 0; d < (p.ablate >> 8); ++d) __builtin_amdgcn_s_sleep(127);
+    }
     const int m0 = tile_m * TM, n0 = tile_n * TN;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int K = min(p.K, kbeg + p.k_per_split);   // this split's k range is [kbeg, K)

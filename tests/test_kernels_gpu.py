@@ -539,3 +539,66 @@ def test_dense_bwd_params(ops, dtype, T, n_out, n_in, sk):
     ops.dense_bwd_params(dy_t, x_t, dw, db, accumulate=True, split_k=sk)
     assert_close(host(dw), 2 * host(w0), 1e-6, "dW accumulate")
     assert_close(host(db), 2 * host(b0), 1e-6, "db accumulate")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 384, 128), (2048, 768, 768), (300, 400, 192), (1000, 192, 1536),
+                                   (4096, 768, 3072)])
+def test_gemm_persistent_256x192(ops, M, N, K, monkeypatch):
+    """gemm_p.hip (persistent 256x192, one workgroup per CU): every epilogue mode it is built for,
+    interior / ragged / several-tiles-per-workgroup shapes, against the oracle arithmetic and
+    bit-for-bit against the ring kernel (same MFMA k-order)."""
+    r = rng(M + 7 * N + K)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.1
+    bias, R, U = r.standard_normal(N), r.standard_normal((M, N)), r.standard_normal((M, N))
+    dt = torch.bfloat16
+    a_t, b_t, bias_t, r_t, u_t = dev(A, dt), dev(B, dt), dev(bias, torch.float32), dev(R, dt), dev(U, dt)
+    base = rounded(A, dt) @ rounded(B, dt).T
+    tol = TOL[dt]
+
+    def both(**kw):
+        outs = []
+        for sel in ("2", "0"):
+            monkeypatch.setenv("POLUS_GEMM_P", sel)
+            out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+            kw2 = dict(kw)
+            if kw2.get("aux") == "new":
+                kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+            ops.gemm(a_t, b_t, out, **kw2)
+            outs.append((out, kw2.get("aux")))
+        monkeypatch.delenv("POLUS_GEMM_P")
+        assert torch.equal(outs[0][0], outs[1][0]), "persistent kernel differs from the ring kernel"
+        return outs[0]
+
+    out, _ = both(bias=bias_t)
+    assert_close(host(out), base + bias, tol, "bias")
+    out, aux = both(bias=bias_t, aux="new", act="gelu", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(aux), base + bias, tol, "aux")
+    assert_close(host(out), ob.gelu(base + bias), tol, "gelu")
+    out, _ = both(bias=bias_t, resid=r_t)
+    assert_close(host(out), base + bias + rounded(R, dt), tol, "bias+resid")
+    out, _ = both(aux=u_t, act="gelu", flags=ops.GEMM_ACT_BWD)
+    assert_close(host(out), base * ob.gelu_grad(rounded(U, dt)), tol, "gelu bwd")
+    out, _ = both(bias=bias_t, resid=r_t, drop_p=0.25, seed=123)
+    keep = host(ops.dropout_mask(123, 0.25, M * N)).astype(np.float64).reshape(M, N)
+    assert_close(host(out), (base + bias) * keep / 0.75 + rounded(R, dt), tol, "dropout+resid")
+
+
+def test_gelu_polynomial_epilogue_precision(ops):
+    """The bf16 GEMM epilogues evaluate GELU / GELU' by a degree-10 polynomial in x^2 (no erf, no
+    exp): through an identity product the error against the exact erf form must stay below a
+    bf16 ulp of the result over the whole range, including the clamped tails."""
+    n = 512
+    x = np.linspace(-9.0, 9.0, 256 * n).reshape(256, n)
+    dt = torch.bfloat16
+    eye = dev(np.eye(n), dt)
+    x_t = dev(x, dt)
+    xr = rounded(x, dt)
+    out = torch.empty((256, n), dtype=dt, device="cuda")
+    ops.gemm(x_t, eye, out, act="gelu", flags=ops.GEMM_ACT_FWD)
+    ref = ob.gelu(xr)
+    assert np.abs(host(out) - ref).max() <= 2.0 ** -8 * np.maximum(np.abs(ref), 2.0 ** -4).max()
+    assert np.all(np.abs(host(out) - ref) <= 2.0 ** -8 * np.maximum(np.abs(ref), 2.0 ** -5))
+    ones = dev(np.ones((256, n)), dt)
+    ops.gemm(ones, eye, out, aux=x_t, act="gelu", flags=ops.GEMM_ACT_BWD)
+    refg = ob.gelu_grad(xr)
+    assert np.all(np.abs(host(out) - refg) <= 2.0 ** -8 * np.maximum(np.abs(refg), 2.0 ** -5))

@@ -7,7 +7,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOT = ["gemm_ring.hip", "gemm256.hip", "gemm.hip", "attention.hip"]
+HOT = ["gemm_p.hip", "gemm_ring.hip", "gemm256.hip", "gemm.hip", "attention.hip"]
 bad = 0
 with tempfile.TemporaryDirectory() as td:
     for f in HOT:

@@ -56,6 +56,9 @@ def main():
             "bias": lambda: ops.gemm(a, b, c, bias=bias),
             "bias+gelu+aux": lambda: ops.gemm(a, b, c, bias=bias, aux=aux, act="gelu", flags=ops.GEMM_ACT_FWD),
             "bias+resid": lambda: ops.gemm(a, b, c, bias=bias, resid=res),
+            "bias+relu+aux": lambda: ops.gemm(a, b, c, bias=bias, aux=aux, act="relu", flags=ops.GEMM_ACT_FWD),
+            "gelu-bwd(aux)": lambda: ops.gemm(a, b, c, aux=aux, act="gelu", flags=ops.GEMM_ACT_BWD),
+            "relu-bwd(aux)": lambda: ops.gemm(a, b, c, aux=aux, act="relu", flags=ops.GEMM_ACT_BWD),
         }
         for vname, fn in variants.items():
             t3 = bench(fn, args.iters)
