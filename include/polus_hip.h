@@ -204,6 +204,13 @@ int polus_clip_scale(const float* sqnorm, float grad_scale, float clip_norm, flo
 int polus_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 /* dst[cols][rows] = src[rows][cols]^T for bf16 (transposed weight shadow read by dX = dY . W) */
 int polus_transpose_bf16(const void* src, void* dst, int rows, int cols, void* stream);
+/* Many matrices at once: matrix s lives at element offset segs[4s] of BOTH src_base and dst_base
+ * (rows segs[4s+1], cols segs[4s+2]); segs[4s+3] = index of its first 64x64 tile in the launch
+ * (ascending), total_tiles = sum of tiles.  `segs_dev` is a device array of 4*nseg int64.  Used
+ * once per optimizer step to refresh the transposed bf16 weight shadows that dX = dY.W reads
+ * (replaces the implicit transpose inside tape.gradient's MatMul grad, polus/training.py:185). */
+int polus_transpose_bf16_batched(const void* src_base, void* dst_base, const void* segs_dev, int nseg,
+                                 int total_tiles, void* stream);
 /* du = dy * act'(u) elementwise (activation gradient of a Dense whose dY is not produced by
  * a polus_gemm epilogue) */
 int polus_act_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n, int act, void* stream);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "polus_scale": (_i, [_vp, _f, _i64, _vp]),
     "polus_act_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i, _vp]),
     "polus_transpose_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "polus_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
 }
 
 

@@ -93,6 +93,34 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
     }
 }
 
+// Same for many matrices that live at the same element offsets of two flat arenas (the bf16 weight
+// shadow and its transposed twin): one launch per optimizer step instead of one per weight.
+// segs[s] = {element offset, rows, cols, first tile}; tiles are 64x64, row-major over the matrix.
+__global__ __launch_bounds__(256) void transpose16_batched_kernel(const unsigned short* __restrict__ src,
+                                                                 unsigned short* __restrict__ dst,
+                                                                 const long* __restrict__ segs, int nseg) {
+    __shared__ unsigned short tile[64][66];
+    const int b = blockIdx.x;
+    int s = 0;
+    while (s + 1 < nseg && segs[4 * (s + 1) + 3] <= b) ++s;     // uniform scan (tens of entries)
+    const long off = segs[4 * s];
+    const int R = (int)segs[4 * s + 1], C = (int)segs[4 * s + 2];
+    const int t = b - (int)segs[4 * s + 3], tc = (C + 63) / 64;
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    const unsigned short* sp = src + off;
+    unsigned short* dp = dst + off;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4) {
+        int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? sp[(long)r * C + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4) {
+        int c = c0 + k, r = r0 + tx;
+        if (c < C && r < R) dp[(long)c * R + r] = tile[tx][k];
+    }
+}
+
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, unsigned seed, unsigned thresh, float inv) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +186,15 @@ extern "C" int polus_act_bwd(int dtype, const void* dy, const void* u, void* du,
         hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(stream_grid(n)), dim3(256), 0, st, (const float*)dy, (const float*)u, (float*)du, n, act);
     else POLUS_FAIL("polus_act_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_act_bwd");
+    return POLUS_OK;
+}
+
+extern "C" int polus_transpose_bf16_batched(const void* src_base, void* dst_base, const void* segs_dev, int nseg,
+                                            int total_tiles, void* stream) {
+    POLUS_REQUIRE(src_base && dst_base && segs_dev && nseg > 0 && total_tiles > 0, "polus_transpose_bf16_batched: bad arguments");
+    hipLaunchKernelGGL(transpose16_batched_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const unsigned short*)src_base, (unsigned short*)dst_base, (const long*)segs_dev, nseg);
+    POLUS_CHECK_LAUNCH("polus_transpose_bf16_batched");
     return POLUS_OK;
 }
 

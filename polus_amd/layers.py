@@ -49,8 +49,12 @@ def dw_split_k(out_rows, out_cols, contraction):
 
 
 def gemm_dx(dy, w, dx, **kw):
-    """dX = dY . W for W stored [out, in]: W is the K-strided operand (k-major LDS image read
-    with the transposing LDS read), so no transposed copy of the weights exists."""
+    """dX = dY . W for W stored [out, in].  bf16 engine: the transposed shadow W^T [in, out]
+    (refreshed once per optimizer step) is a K-contiguous B operand; otherwise W itself is the
+    K-strided operand (k-major LDS image, transposing LDS reads)."""
+    wt = w.compute_t
+    if wt is not None:
+        return ops.gemm(dy, wt, dx, **kw)
     return ops.gemm(dy, w.compute, dx, b_layout=ops.K_STRIDED, **kw)
 
 

@@ -289,6 +289,14 @@ def transpose_bf16(src, dst):
     check(_lib.load().polus_transpose_bf16(ptr(src), ptr(dst), R, C, _st()), "polus_transpose_bf16")
 
 
+def transpose_bf16_batched(src_base, dst_base, segs_dev, nseg, total_tiles):
+    """All matrices of a flat bf16 arena into its transposed twin in one launch (segs: int64 [nseg, 4])."""
+    _req_cuda(src_base, dst_base, segs_dev)
+    assert src_base.dtype == torch.bfloat16 and dst_base.dtype == torch.bfloat16 and segs_dev.dtype == torch.int64
+    check(_lib.load().polus_transpose_bf16_batched(ptr(src_base), ptr(dst_base), ptr(segs_dev), int(nseg), int(total_tiles), _st()),
+          "polus_transpose_bf16_batched")
+
+
 def dense_bwd_params(dy, x, dw, db, accumulate=False, split_k=1):
     """dW (+)= dY^T X and db (+)= colsum(dY) in one pass over dY."""
     lib = _lib.load()

@@ -457,15 +457,22 @@ def test_gemm256_epilogues_and_identity(ops):
     assert np.array_equal(host(o), rounded(Bm, dt).T)
 
 
-def _disabled_transposed_shadow_dx(ops):
+def test_transposed_shadow_dx(ops):
+    """bf16 engine: dX = dY . W reads the transposed weight shadow, refreshed for all matrices by
+    one batched launch (ragged 64x64 tiles, several matrices at different arena offsets)."""
     from polus_amd.layers import gemm_dx
     from polus_amd.tensor import ParamArena
     arena = ParamArena(torch.bfloat16)
     r = rng(31)
     W = r.standard_normal((320, 256)) * 0.1
+    others = [arena.add("a", (70, 130), r.standard_normal((70, 130)).astype(np.float32), matrix=True),
+              arena.add("bias", (130,), np.zeros(130, np.float32))]
     w = arena.add("w", (320, 256), W.astype(np.float32), matrix=True)
+    others.append(arena.add("z", (33, 5), r.standard_normal((33, 5)).astype(np.float32), matrix=True))
     arena.finalize()
-    assert torch.equal(w.compute_t, w.compute.t().contiguous())
+    for v in [others[0], w, others[2]]:
+        assert torch.equal(v.compute_t, v.compute.t().contiguous()), v.name
+    assert others[1].compute_t is None
     dY = r.standard_normal((512, 320))
     dx = torch.empty((512, 256), dtype=torch.bfloat16, device="cuda")
     gemm_dx(dev(dY, torch.bfloat16), w, dx)
