@@ -138,6 +138,32 @@ __device__ __forceinline__ void colacc_flush(const ColAcc<NC>& a, float* lds /*[
     for (int idx = threadIdx.x; idx < n; idx += blockDim.x) dst[idx] = lds[idx];
 }
 
+// Same for small workgroups (W waves): every wave drops its sums into its own LDS slice
+// [W][3H], then all threads add the W slices in fixed order -- one barrier instead of W.
+template <int NC, int W>
+__device__ __forceinline__ void colacc_flush_par(const ColAcc<NC>& a, float* lds /*[W][3*H]*/, float* partial, int H,
+                                                 int lane, int wid, int want_bias) {
+    float* mine = lds + (long)wid * 3 * H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int col = (lane + 64 * c) * 4;
+        if (col < H) {
+            *reinterpret_cast<float4*>(mine + col) = make_float4(a.dg[c][0], a.dg[c][1], a.dg[c][2], a.dg[c][3]);
+            *reinterpret_cast<float4*>(mine + H + col) = make_float4(a.db[c][0], a.db[c][1], a.db[c][2], a.db[c][3]);
+            *reinterpret_cast<float4*>(mine + 2 * H + col) = make_float4(a.dbias[c][0], a.dbias[c][1], a.dbias[c][2], a.dbias[c][3]);
+        }
+    }
+    __syncthreads();
+    float* dst = partial + (long)blockIdx.x * 3 * H;
+    int n = (want_bias ? 3 : 2) * H;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        float t = lds[idx];
+#pragma unroll
+        for (int w = 1; w < W; ++w) t += lds[(long)w * 3 * H + idx];
+        dst[idx] = t;
+    }
+}
+
 template <typename T, typename TDX, int NC>
 __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dyrow, const float (&gv)[NC][4],
                                            TDX* dxrow, int H, int lane, float mu, float rs, ColAcc<NC>& acc,
@@ -194,8 +220,11 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
     }
 }
 
+// LayerNorm backward proper runs 4-wave workgroups (up to 1024 of them: shorter tail, cheap
+// flush); its [blocks][3H] partials are reduced in two fixed-order stages.
+constexpr int BWD_WAVES = 4, BWD_MAX_BLOCKS = 1024, FIN_GROUP = 128;
 template <typename T, int NC>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(64 * BWD_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      float* __restrict__ partial, int rows, int H, int want_bias,
@@ -207,24 +236,32 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const T* __restrict_
     colacc_zero(acc);
     float gv[NC][4];
     load_feat<NC>(gamma, H, lane, gv);
-    for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
+    for (int row = blockIdx.x * BWD_WAVES + wid; row < rows; row += gridDim.x * BWD_WAVES) {
         float xv[NC][4];
         load_row<T, NC>(x + (long)row * H, H, lane, xv);
         ln_bwd_row<T, T, NC>(xv, dy + (long)row * H, gv, dx + (long)row * H, H, lane, mean[row], rstd[row], acc, want_bias,
                              dxm ? dxm + (long)row * H : nullptr, drop, DropArgs{0, 0, 1.f}, (unsigned)row * (unsigned)H);
     }
-    colacc_flush(acc, lds, partial, H, lane, wid, want_bias);
+    colacc_flush_par<NC, BWD_WAVES>(acc, lds, partial, H, lane, wid, want_bias);
 }
 
 // out_k[c] (+)= sum_p partial[p][k*seg + c]: 64 columns x 16 partial groups per block,
 // groups combined in fixed order.
+// blockIdx.y selects a group of `pgroup` consecutive partial rows (first stage of a two-stage
+// reduction: out0 then is a [groups][ncols] array, seg = ncols, written at row blockIdx.y).
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ partial, int P, int pstride,
                                                                int ncols, int seg, float* out0, float* out1,
-                                                               float* out2, int accumulate) {
+                                                               float* out2, int accumulate, int pgroup = 0) {
     __shared__ float red[16][64];
     const int cx = threadIdx.x & 63, gy = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cx;
     float s = 0.f;
+    if (pgroup > 0) {
+        const int p0 = blockIdx.y * pgroup;
+        partial += (long)p0 * pstride;
+        P = min(pgroup, P - p0);
+        out0 += (long)blockIdx.y * ncols;
+    }
     if (col < ncols)
         for (int p = gy; p < P; p += 16) s += partial[(long)p * pstride + col];
     red[gy][cx] = s;
@@ -304,6 +341,10 @@ int colsum_launch(int dtype, const void* x, long ldx, int rows, int cols, float*
         else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                  \
     } while (0)
 
+int ln_bwd_blocks(int rows) {
+    int b = (rows + BWD_WAVES - 1) / BWD_WAVES;
+    return b > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : (b < 1 ? 1 : b);
+}
 int ln_blocks(int rows) {
     int b = (rows + WAVES - 1) / WAVES;
     return b > MAX_PARTIAL_BLOCKS ? MAX_PARTIAL_BLOCKS : (b < 1 ? 1 : b);
@@ -451,7 +492,12 @@ __global__ __launch_bounds__(256) void embed_pos_grad_kernel(const float* __rest
 }  // namespace
 
 extern "C" size_t polus_layernorm_bwd_workspace_bytes(int rows, int H) {
-    return (size_t)ln_blocks(rows) * 3 * (size_t)H * sizeof(float);
+    // [blocks][3H] block partials (max of the two users: LayerNorm proper, embedding LayerNorm)
+    // + [groups][3H] second-stage partials
+    int b = ln_bwd_blocks(rows), b2 = ln_blocks(rows);
+    if (b2 > b) b = b2;
+    int groups = (b + FIN_GROUP - 1) / FIN_GROUP;
+    return ((size_t)b + groups) * 3 * (size_t)H * sizeof(float);
 }
 
 extern "C" int polus_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta,
@@ -487,19 +533,31 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
     size_t need = polus_layernorm_bwd_workspace_bytes(rows, H);
     if (!workspace || workspace_bytes < need) { polus_set_error("polus_layernorm_bwd: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int blocks = ln_blocks(rows);
+    int blocks = ln_bwd_blocks(rows);
     float* partial = static_cast<float*>(workspace);
-    size_t lds = 3 * (size_t)H * sizeof(float);
+    size_t lds = (size_t)BWD_WAVES * 3 * (size_t)H * sizeof(float);
     int wb = dbias ? 1 : 0;
     if (dtype == POLUS_BF16)
-        POLUS_NC_DISPATCH(H, bf16_t, ln_bwd_kernel, dim3(blocks), dim3(LN_THREADS), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb, (bf16_t*)dx_masked, drop);
+        POLUS_NC_DISPATCH(H, bf16_t, ln_bwd_kernel, dim3(blocks), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb, (bf16_t*)dx_masked, drop);
     else if (dtype == POLUS_F32)
-        POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(LN_THREADS), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb, (float*)dx_masked, drop);
+        POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(64 * BWD_WAVES), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb, (float*)dx_masked, drop);
     else POLUS_FAIL("polus_layernorm_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd");
     int ncols = (wb ? 3 : 2) * H;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, st,
-                       partial, blocks, 3 * H, ncols, H, dgamma, dbeta, dbias, accumulate);
+    if (blocks > 2 * FIN_GROUP) {
+        // two fixed-order stages: [blocks] -> [groups] -> result (a single stage would leave most
+        // of the chip idle: ncols/64 workgroups walking 1024 rows each)
+        int groups = (blocks + FIN_GROUP - 1) / FIN_GROUP;
+        float* part2 = partial + (size_t)blocks * 3 * H;
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64, groups), dim3(1024), 0, st,
+                           partial, blocks, 3 * H, ncols, ncols, part2, (float*)nullptr, (float*)nullptr, 0, FIN_GROUP);
+        POLUS_CHECK_LAUNCH("polus_layernorm_bwd(finalize 1)");
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, st,
+                           part2, groups, ncols, ncols, H, dgamma, dbeta, dbias, accumulate, 0);
+    } else {
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, st,
+                           partial, blocks, 3 * H, ncols, H, dgamma, dbeta, dbias, accumulate, 0);
+    }
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd(finalize)");
     return POLUS_OK;
 }
