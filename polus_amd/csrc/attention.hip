@@ -22,6 +22,8 @@ namespace {
 constexpr int D = 64;        // head dim
 constexpr int BLK = 64;      // rows per LDS tile / per workgroup
 constexpr float MASK_NEG = -10000.0f;
+// exponentials run in base 2 (v_exp_f32 is 2^x): scale and key bias carry log2(e), one FMA per score
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 template <typename T> struct TileCfg;
 template <> struct TileCfg<bf16_t> { static constexpr int RS = 160, EPC = 8, LOG_CPR = 3, NLOAD = 2; };
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int sub = 0; sub < 2; ++sub)
         frag_global<T>(qf[sub], qkv + (long)q * ld + h * D + sub * 32 + 8 * g, qvalid);
 
+    const float scale2 = p.scale * LOG2E;
     float m = -1e30f, l = 0.f;
     f32x4 o[4];
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         __syncthreads();
         tile_load<T>(Kt, qkv, ld, kb0, S, H + h * D, tid);
         tile_load<T>(Vt, qkv, ld, kb0, S, 2 * H + h * D, tid);
-        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid);
+        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid) * LOG2E;
         __syncthreads();
 
         f32x4 s[4];
@@ -168,17 +171,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[kt][r] = s[kt][r] * p.scale + kbias[kt * 16 + 4 * g + r];
+                s[kt][r] = fmaf(s[kt][r], scale2, kbias[kt * 16 + 4 * g + r]);   // log2 units
                 mx = fmaxf(mx, s[kt][r]);
             }
         mx = col_max(mx);
         const float m_new = fmaxf(m, mx);
-        const float alpha = __expf(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m_new); rs += s[kt][r]; }
+            for (int r = 0; r < 4; ++r) { s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m_new); rs += s[kt][r]; }
         rs = col_sum(rs);
         l = l * alpha + rs;
         m = m_new;
@@ -189,10 +192,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         if (p.drop_thresh) {   // the row sum above used the undropped probabilities (softmax first, then dropout)
             const unsigned rowb = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb0 + 4 * g;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    s[kt][r] = polus_keep(p.drop_seed, rowb + kt * 16 + r, p.drop_thresh) ? s[kt][r] * p.drop_inv : 0.f;
+            for (int kt = 0; kt < 4; ++kt) {
+                float t4[4] = {s[kt][0], s[kt][1], s[kt][2], s[kt][3]};
+                polus_dropout_run<4>(t4, p.drop_seed, rowb + kt * 16, p.drop_thresh, p.drop_inv, (S & 1) == 0);
+                s[kt] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
     T* ctx = static_cast<T*>(p.ctx) + (long)b * S * H;
     store_acc_T<T>(ctx, H, q, h * D, o, 1.0f / l, g, qvalid);
-    if (qvalid && g == 0) p.lse[((long)b * p.A + h) * S + q] = m + __logf(l);
+    if (qvalid && g == 0) p.lse[((long)b * p.A + h) * S + q] = m * LN2 + __logf(l);
 }
 
 // ---------------------------------------------------------------- delta = rowsum(dO * O) per head
@@ -254,7 +258,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         frag_global<T>(dof[sub], dctx + (long)q * H + h * D + sub * 32 + 8 * g, qvalid);
     }
     const long stat = ((long)b * p.A + h) * S + q;
-    const float lse = qvalid ? p.lse[stat] : 0.f;
+    const float lse2 = (qvalid ? p.lse[stat] : 0.f) * LOG2E;
+    const float scale2 = p.scale * LOG2E;
     const float dl = qvalid ? p.delta[stat] : 0.f;
 
     f32x4 dq[4];
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         __syncthreads();
         tile_load<T>(Kt, qkv, ld, kb0, S, H + h * D, tid);
         tile_load<T>(Vt, qkv, ld, kb0, S, 2 * H + h * D, tid);
-        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid);
+        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid) * LOG2E;
         __syncthreads();
         f32x4 s[4], dp[4];
 #pragma unroll
@@ -280,14 +285,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
                 frag_row<T>(a, Vt, kt * 16 + i, sub, g);
                 mma16(dp[kt], a, dof[sub]);
             }
+            if (p.drop_thresh) {
+                float t4[4] = {dp[kt][0], dp[kt][1], dp[kt][2], dp[kt][3]};
+                const unsigned idx0 = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb0 + kt * 16 + 4 * g;
+                polus_dropout_run<4>(t4, p.drop_seed, idx0, p.drop_thresh, p.drop_inv, (S & 1) == 0);
+                dp[kt] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float pr = __expf(s[kt][r] * p.scale + kbias[kt * 16 + 4 * g + r] - lse);
+                float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale2, kbias[kt * 16 + 4 * g + r]) - lse2);
                 float dpe = dp[kt][r];
-                if (p.drop_thresh) {
-                    const unsigned idx = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb0 + kt * 16 + 4 * g + r;
-                    dpe = polus_keep(p.drop_seed, idx, p.drop_thresh) ? dpe * p.drop_inv : 0.f;
-                }
                 s[kt][r] = pr * (dpe - dl) * p.scale;  // dS
             }
         }
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // ---------------------------------------------------------------- dK, dV
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kernel(AttnArgs p) {   // bf16: 3 waves per SIMD (<= 168 registers)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + 2 * BLK * 4];
     unsigned char* Qt = smem;
     unsigned char* Ot = smem + BLK * TileCfg<T>::RS;
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         frag_global<T>(kf[sub], qkv + (long)key * ld + H + h * D + sub * 32 + 8 * g, kvalid);
         frag_global<T>(vf[sub], qkv + (long)key * ld + 2 * H + h * D + sub * 32 + 8 * g, kvalid);
     }
-    const float kb = key_bias(p.mask, b, S, key);
+    const float kb2 = key_bias(p.mask, b, S, key) * LOG2E, scale2 = p.scale * LOG2E;
     const long stat0 = ((long)b * p.A + h) * S;
 
     f32x4 dk[4], dv[4];
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         tile_load<T>(Ot, dctx, H, qb0, S, h * D, tid);
         if (tid < BLK) {
             int qq = qb0 + tid;
-            slse[tid] = qq < S ? p.lse[stat0 + qq] : INFINITY;  // exp(-inf) = 0 for padded queries
+            slse[tid] = qq < S ? p.lse[stat0 + qq] * LOG2E : INFINITY;  // exp2(-inf) = 0 for padded queries
             sdelta[tid] = qq < S ? p.delta[stat0 + qq] : 0.f;
         }
         __syncthreads();
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int ql = qt * 16 + 4 * g + r;
-                float pr = __expf(s[qt][r] * p.scale + kb - slse[ql]);
+                float pr = __builtin_amdgcn_exp2f(fmaf(s[qt][r], scale2, kb2) - slse[ql]);
                 float dpe = dp[qt][r], pd = pr;
                 if (p.drop_thresh) {
                     const unsigned idx = (((unsigned)b * p.A + h) * S + (unsigned)(qb0 + ql)) * S + (unsigned)key;

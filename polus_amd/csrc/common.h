@@ -159,8 +159,12 @@ template <int N, bool FAST = false> __device__ __forceinline__ void apply_act_gr
 
 // ---------------------------------------------------------------- dropout (counter-based)
 // keep(seed, idx) is a pure function of (seed, element index): forward and backward regenerate
-// the same mask instead of storing it.  murmur3 finaliser over idx ^ seed; the per-call seed
-// already mixes step / layer / site on the host.  thresh = p * 2^32.
+// the same mask instead of storing it.  One murmur3-finaliser hash serves TWO elements: element
+// idx takes the 16-bit half (idx & 1) of hash(seed, idx >> 1) and is kept when that half is
+// >= thresh = round(p * 65536) (p resolved to 1.5e-5).  The fused epilogues are VALU-bound, and
+// the hash is a third of their work; kernels whose lanes hold an even-aligned run of elements use
+// polus_keep2 (one hash per pair), the rest polus_keep -- same mask either way.  The per-call seed
+// already mixes step / layer / site on the host.
 __device__ __forceinline__ uint32_t polus_hash32(uint32_t seed, uint32_t idx) {
     uint32_t x = idx * 0x9E3779B1u + seed;
     x ^= x >> 16; x *= 0x85EBCA6Bu;
@@ -169,16 +173,34 @@ __device__ __forceinline__ uint32_t polus_hash32(uint32_t seed, uint32_t idx) {
     return x;
 }
 __device__ __forceinline__ bool polus_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
-    return polus_hash32(seed, idx) >= thresh;
+    const uint32_t h = polus_hash32(seed, idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh;
 }
-// two masks per hash (16-bit halves; thresh16 = thresh >> 16): halves the ALU work of the fused
-// epilogues.  Element idx uses half (idx & 1) of hash(seed, idx >> 1).
-__device__ __forceinline__ bool polus_keep16(uint32_t h, int half, uint32_t thresh) {
-    return ((half ? (h >> 16) : (h & 0xFFFFu)) >= (thresh >> 16));
+// idx_even must be even: masks of elements idx_even and idx_even + 1
+__device__ __forceinline__ void polus_keep2(uint32_t seed, uint32_t idx_even, uint32_t thresh, bool& k0, bool& k1) {
+    const uint32_t h = polus_hash32(seed, idx_even >> 1);
+    k0 = (h & 0xFFFFu) >= thresh;
+    k1 = (h >> 16) >= thresh;
+}
+// v[r] = keep(base + r) ? v[r] * inv : 0 for r < N (N even); `even` says base is even (uniform)
+template <int N>
+__device__ __forceinline__ void polus_dropout_run(float (&v)[N], uint32_t seed, uint32_t base, uint32_t thresh, float inv, bool even) {
+    if (even) {
+#pragma unroll
+        for (int r = 0; r < N; r += 2) {
+            bool k0, k1;
+            polus_keep2(seed, base + r, thresh, k0, k1);
+            v[r] = k0 ? v[r] * inv : 0.f;
+            v[r + 1] = k1 ? v[r + 1] * inv : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < N; ++r) v[r] = polus_keep(seed, base + r, thresh) ? v[r] * inv : 0.f;
+    }
 }
 static inline uint32_t polus_drop_thresh(float p) {
-    double t = (double)p * 4294967296.0;
-    return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+    double t = (double)p * 65536.0 + 0.5;
+    return t <= 0.0 ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
 }
 
 // ---------------------------------------------------------------- wave64 reductions

@@ -173,8 +173,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
                 }
                 if (DROP) {
                     const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = polus_keep(p.drop_seed, base + r, p.drop_thresh) ? v[r] * p.drop_inv : 0.0f;
+                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 1) == 0);
                 }
                 if (has_resid) {
 #pragma unroll

@@ -67,10 +67,9 @@ __device__ __forceinline__ void normalize_store(const float (&v)[NC][4], const f
         if (col < H) {
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (v[c][e] - mean) * rstd * gv[c][e] + bv[c][e];
-                if (dthresh) o[e] = polus_keep(dseed, rowbase + col + e, dthresh) ? o[e] * dinv : 0.f;
-            }
+            for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * gv[c][e] + bv[c][e];
+            // rowbase = row * H and col are multiples of 4: even-aligned run
+            if (dthresh) polus_dropout_run<4>(o, dseed, rowbase + col, dthresh, dinv, true);
             store4<T>(y + col, o);
         }
     }
@@ -175,9 +174,7 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             int col = (lane + 64 * c) * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dy[c][e] = polus_keep(in_drop.seed, rowbase + col + e, in_drop.thresh) ? dy[c][e] * in_drop.inv : 0.f;
+            polus_dropout_run<4>(dy[c], in_drop.seed, rowbase + col, in_drop.thresh, in_drop.inv, true);
         }
     }
     float s1 = 0.f, s2 = 0.f;
@@ -208,11 +205,12 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
         if (col < H) {
             float o[4], om[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o[e] = (dxh[c][e] - s1 - xh[c][e] * s2) * rs;
-                // x = dropout(dense) + residual: the Dense (and its bias) see the masked gradient
-                om[e] = out_drop.thresh ? (polus_keep(out_drop.seed, rowbase + col + e, out_drop.thresh) ? o[e] * out_drop.inv : 0.f) : o[e];
-                if (want_bias) acc.dbias[c][e] += om[e];
+            for (int e = 0; e < 4; ++e) { o[e] = (dxh[c][e] - s1 - xh[c][e] * s2) * rs; om[e] = o[e]; }
+            // x = dropout(dense) + residual: the Dense (and its bias) see the masked gradient
+            if (out_drop.thresh) polus_dropout_run<4>(om, out_drop.seed, rowbase + col, out_drop.thresh, out_drop.inv, true);
+            if (want_bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc.dbias[c][e] += om[e];
             }
             store4<TDX>(dxrow + col, o);
             if (dxm_row) store4<TDX>(dxm_row + col, om);
