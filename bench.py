@@ -167,10 +167,16 @@ def main():
     # (every rank takes the step -- it contains the gradient all-reduce -- only rank 0 records)
     roof = None
     rec = []
+    # The dW GEMMs normally run beside the dX GEMMs on a side stream; events around a launch would
+    # then time two kernels sharing the CUs, so this one step keeps everything on one stream (as
+    # the rocprof summaries under profiles/ do with POLUS_OVERLAP_DW=0).
     if rank == 0:
         ops.GEMM_PROFILE = rec
+    overlap = getattr(model, "overlap_dw", False)
+    model.overlap_dw = False
     one_step(args.warmup + args.steps)
     torch.cuda.synchronize()
+    model.overlap_dw = overlap
     ops.GEMM_PROFILE = None
     if rank == 0:
         fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for (key, fl, e0, e1) in rec if key == "fwd"]
@@ -180,14 +186,15 @@ def main():
             peak = PEAK_TFLOPS[args.dtype]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
-                    "kernel": ("gemm_ring_kernel<bf16, A K-contig, B K-contig>" if args.dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig>")
-                              + " (forward Dense: QKV, out-proj, FFN1, FFN2; with and without the dropout epilogue)",
+                    "kernel": ("gemm_ring_kernel<bf16, K-contig, K-contig> / gemm_p_kernel<192>" if args.dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig>")
+                              + " (every K-contiguous Dense GEMM of the step: forward QKV, out-proj, FFN1, FFN2 and their"
+                                " input gradients dX = dY.W^T-shadow; the remaining GEMMs are the K-strided dW = dY^T.X)",
                     "launches": len(fwd), "avg_launch_us": round(tsum / len(fwd) * 1e6, 2),
                     "flops_per_launch": fsum / len(fwd)}
             tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
             if args.dtype == "bf16" and os.path.exists(tf) and (B, S, L, H) == (64, 256, 12, 768):
                 # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (FETCH_SIZE x2
-                # gfx950 correction, WRITE_SIZE), see profiles/README.md
+                # gfx950 correction, WRITE_SIZE) reduced by tools/hbm_traffic.py, see profiles/README.md
                 roof["traffic"] = json.load(open(tf))["bytes_per_launch"]
             allg = [(e0.elapsed_time(e1) * 1e-3, fl) for (_, fl, e0, e1) in rec]
             roof["all_gemm_tflops"] = round(sum(f for _, f in allg) / sum(t for t, _ in allg) / 1e12, 2)
