@@ -95,6 +95,23 @@ int polus_dense_bwd_params(int dtype, const void* dY, long lddy, const void* X, 
                            int accumulate, int split_k, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* The same for up to POLUS_MAX_GROUP (8) Dense layers in ONE launch -- the four weight gradients of
+ * an encoder layer (the per-variable MatMul grads tape.gradient emits for one TFBertLayer,
+ * polus/training.py:185 through polus/models.py:205-213): the concatenated tile lists fill the chip
+ * with 1-2 K-splits instead of 7-28 per matrix.  All problems share T, `accumulate` and `split_k`;
+ * db may be NULL per problem.  Falls back to one call per problem when a shape does not fit the
+ * grouped kernel. */
+typedef struct polus_dw_problem {
+    const void* dY; long lddy;     /* [T, n_out] */
+    const void* X;  long ldx;      /* [T, n_in]  */
+    float* dW; long lddw;          /* [n_out, n_in] f32 */
+    float* db;                     /* [n_out] f32 or NULL */
+    int n_out, n_in;
+} polus_dw_problem;
+size_t polus_dense_bwd_params_grouped_workspace_bytes(int n, const polus_dw_problem* problems, int T, int split_k);
+int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_problem* problems, int T, int accumulate,
+                                   int split_k, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused scaled-dot-product attention (HF TFBertSelfAttention as driven by
  * TFBertSplited.call, polus/models.py:201-216, with the additive key mask
  * (1-m)*-10000 of polus/models.py:175-195).

@@ -62,7 +62,16 @@ SIGNATURES = {
     "polus_act_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i, _vp]),
     "polus_transpose_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "polus_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "polus_dense_bwd_params_grouped_workspace_bytes": (_sz, [_i, _vp, _i, _i]),
+    "polus_dense_bwd_params_grouped": (_i, [_i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
 }
+
+
+class DwProblem(ctypes.Structure):
+    """struct polus_dw_problem of include/polus_hip.h"""
+    _fields_ = [("dY", ctypes.c_void_p), ("lddy", ctypes.c_long), ("X", ctypes.c_void_p), ("ldx", ctypes.c_long),
+                ("dW", ctypes.c_void_p), ("lddw", ctypes.c_long), ("db", ctypes.c_void_p),
+                ("n_out", ctypes.c_int), ("n_in", ctypes.c_int)]
 
 
 class PolusHipError(RuntimeError):

@@ -25,6 +25,7 @@
 // 32-byte unit index inside a k-row is XORed with (k&3) | ((k>>3)&1)<<2 on the DMA source side
 // and on the read side, so the 8 k-rows a half-wave reads fall on 8 distinct 32-byte bank
 // windows.  Split-K over blockIdx.y writes f32 slabs reduced by an order-fixed second kernel.
+#include <cstddef>
 #include "gemm_common.h"
 
 using namespace pgemm;
@@ -47,8 +48,9 @@ __device__ __forceinline__ int pi4(int q) { return (0x78 >> (2 * q)) & 3; }
 #define POLUS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define POLUS_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// One 256x128 output tile (workgroup `wg` of the `nwg` that cover the problem) of K-split `split`.
 template <typename TC, bool A_KS, bool B_KS, bool DROP>
-__global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
+__device__ __forceinline__ void ring_body(const GemmArgs& p, const int wg_in, const int nwg, const int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,23 +58,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
     const int wm = wid >> 1, wn = wid & 1;
 
     const int tiles_n = (p.N + TN - 1) / TN;
-    int tile_m, tile_n;
-    if ((p.ablate & 4) && gridDim.x == 512 && (tiles_n & 1) == 0) {
-        // experiment: the two workgroups that share a CU (b, b+256) take n-adjacent tiles (same A rows)
-        const int c = blockIdx.x & 255, h = blockIdx.x >> 8;
-        const int P = xcd_remap(c, 256);
-        tile_m = P / (tiles_n >> 1);
-        tile_n = 2 * (P % (tiles_n >> 1)) + h;
-    } else {
-        const int wg = xcd_remap(blockIdx.x, gridDim.x);
-        tile_m = wg / tiles_n; tile_n = wg % tiles_n;
-    }
-    if ((p.ablate & 8) && blockIdx.x >= 256 && blockIdx.x < 512 && blockIdx.y == 0) {
-        // experiment: break the lock-step of the two workgroups of a CU (delay in units of ~3.4 us)
-        for (int d = 0; d < (p.ablate >> 8); ++d) __builtin_amdgcn_s_sleep(127);
-    }
+    const int wg = xcd_remap(wg_in, nwg);
+    const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * TN;
-    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kbeg = split * p.k_per_split;
     const int K = min(p.K, kbeg + p.k_per_split);   // this split's k range is [kbeg, K)
     const int nk = (K - kbeg + TK - 1) / TK;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_chunk_ring);
@@ -213,11 +202,59 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             const int m = m0 + wm * 128 + mt * 16 + i;
-            if (m < p.M) p.colsum_a[(long)blockIdx.y * p.M + m] = csum[mt][0];
+            if (m < p.M) p.colsum_a[(long)split * p.M + m] = csum[mt][0];
         }
     }
-    p.C = static_cast<TC*>(p.C) + (long)blockIdx.y * p.c_split_stride;
-    epilogue_wave_128x64_lds<TC, DROP>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    GemmArgs q = p;
+    q.C = static_cast<TC*>(p.C) + (long)split * p.c_split_stride;
+    epilogue_wave_128x64_lds<TC, DROP>(q, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+}
+
+template <typename TC, bool A_KS, bool B_KS, bool DROP>
+__global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
+    ring_body<TC, A_KS, B_KS, DROP>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Several problems with the same contraction length in one launch (the dW = dY^T X of all four
+// Dense layers of an encoder layer): blockIdx.x runs over the concatenated tile lists (each
+// problem's range padded to a multiple of 8 so that workgroup index mod 8 stays the XCD),
+// blockIdx.y over the K-splits.  One problem alone leaves most of the 512 workgroup slots
+// empty unless K is cut into many splits, each of which costs an f32 slab to write and re-read.
+struct RingGroupArgs {
+    GemmArgs p[POLUS_MAX_GROUP];
+    int tile0[POLUS_MAX_GROUP + 1];   // first workgroup of each problem (padded), ascending
+    int tiles[POLUS_MAX_GROUP];       // real tiles of each problem
+    int n;
+};
+template <typename TC, bool A_KS, bool B_KS>
+__global__ __launch_bounds__(NTHR, 2) void gemm_ring_grouped_kernel(RingGroupArgs ga) {
+    const int b = blockIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < POLUS_MAX_GROUP; ++k)
+        if (k < ga.n && b >= ga.tile0[k]) q = k;
+    const int wg = b - ga.tile0[q];
+    if (wg >= ga.tiles[q]) return;          // padding workgroup
+    // ga.p[q] with a run-time q would put the by-value argument array into scratch: read the
+    // chosen problem straight out of the kernarg segment (scalar loads) into a local copy instead
+    typedef const __attribute__((address_space(4))) unsigned char* karg_t;
+    karg_t ka = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    GemmArgs P;
+    {
+        static_assert(sizeof(GemmArgs) % 4 == 0, "GemmArgs is copied word by word");
+        const __attribute__((address_space(4))) uint32_t* src =
+            reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(ka + offsetof(RingGroupArgs, p) + (size_t)q * sizeof(GemmArgs));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&P);
+#pragma unroll
+        for (int w = 0; w < (int)(sizeof(GemmArgs) / 4); ++w) dst[w] = src[w];
+        // the word copy hides that these are global pointers (flat loads/stores otherwise)
+typedef __attribute__((address_space(1))) void gvoid_t;
+        typedef __attribute__((address_space(1))) float gfloat_t;
+        P.A = (const void*)(const gvoid_t*)P.A; P.B = (const void*)(const gvoid_t*)P.B; P.C = (void*)(gvoid_t*)P.C;
+        P.bias = (const float*)(const gfloat_t*)P.bias; P.resid = (const void*)(const gvoid_t*)P.resid;
+        P.aux = (void*)(gvoid_t*)P.aux; P.partial = (float*)(gfloat_t*)P.partial; P.colsum_a = (float*)(gfloat_t*)P.colsum_a;
+    }
+    ring_body<TC, A_KS, B_KS, false>(P, wg, ga.tiles[q], blockIdx.y);
 }
 
 template <typename TC, bool A_KS, bool B_KS, bool DROP = false>
@@ -244,6 +281,30 @@ int launch_layout(const GemmArgs& a, int a_ks, int b_ks, int splits, hipStream_t
 }
 
 }  // namespace
+
+int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, int splits, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_ring_grouped_kernel<float, true, true>;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        attr_done = true;
+    }
+    RingGroupArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.n = n;
+    int t0 = 0;
+    for (int k = 0; k < n; ++k) {
+        ga.p[k] = probs[k];
+        ga.tiles[k] = ((probs[k].M + TM - 1) / TM) * ((probs[k].N + TN - 1) / TN);
+        ga.tile0[k] = t0;
+        t0 += (ga.tiles[k] + 7) / 8 * 8;
+    }
+    ga.tile0[n] = t0;
+    hipLaunchKernelGGL(kern, dim3(t0, splits), dim3(NTHR), SMEM_BYTES, st, ga);
+    POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(ring)");
+    return POLUS_OK;
+}
 
 int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
     return launch_ring<bf16_t, false, false, true>(a, 1, st);

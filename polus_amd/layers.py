@@ -6,6 +6,7 @@ Mirrors the Keras layers the reference composes (tutorials/classifier_example.py
 polus/ner/models.py:35-39) and polus/layers.py CRF.
 """
 import math
+import os
 import zlib
 
 import numpy as np
@@ -46,6 +47,31 @@ def dw_split_k(out_rows, out_cols, contraction):
     tiles = ((out_rows + 255) // 256) * ((out_cols + 127) // 128)
     want = max(1, 512 // max(tiles, 1))
     return int(max(1, min(want, contraction // 256, 64)))
+
+
+def dw_group_split_k(shapes, contraction):
+    """Split-K factor for one grouped dW launch over `shapes` = [(n_out, n_in), ...]: the
+    concatenated 256x128 tile lists (each padded to a multiple of 8) times the splits should
+    fill the 512 workgroup slots once."""
+    tiles = sum((((o + 255) // 256) * ((i + 127) // 128) + 7) // 8 * 8 for o, i in shapes)
+    want = max(1, 512 // max(tiles, 1))
+    return int(max(1, min(want, contraction // 256, 64)))
+
+
+def dense_bwd_params_group(problems, accumulate=False):
+    """dW (+ db) of several Dense layers that share T: one grouped launch on the bf16 engine; the
+    f32 engine (128x128 exact-f32 kernel) runs them one by one with per-matrix split-K."""
+    T = problems[0][0].shape[0]
+    if problems[0][0].dtype == torch.bfloat16 and os.environ.get("POLUS_DW_UNGROUPED") is None:
+        shapes = [(dy.shape[1], x.shape[1]) for dy, x, _, _ in problems]
+        return ops.dense_bwd_params_grouped(problems, accumulate, dw_group_split_k(shapes, T))
+    for dy, x, dw, db in problems:
+        sk = dw_split_k(dy.shape[1], x.shape[1], T)
+        if db is not None:
+            ops.dense_bwd_params(dy, x, dw, db, accumulate, sk)
+        else:
+            ops.gemm(dy, x, dw, a_layout=ops.K_STRIDED, b_layout=ops.K_STRIDED,
+                     flags=ops.GEMM_ACCUM_C if accumulate else 0, split_k=sk)
 
 
 def gemm_dx(dy, w, dx, **kw):

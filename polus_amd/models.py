@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .layers import CRF, Dense, Dropout, Flatten, Layer, dw_split_k, gemm_dx
+from .layers import CRF, Dense, Dropout, Flatten, Layer, dense_bwd_params_group, gemm_dx
 from .tensor import ParamArena, to_device, device
 
 COMPUTE_DTYPES = {"f32": torch.float32, "float32": torch.float32, torch.float32: torch.float32,
@@ -132,59 +132,53 @@ class BertLayer:
     def backward(self, dy, scratch, accumulate=False, side=None):
         """dy [T,H] -> dx [T,H]; parameter gradients land in the arena (overwritten, or added
         to when `accumulate`).  `scratch(key, shape)` hands out buffers shared by all layers.
-        `side`: a second HIP stream for the four dW GEMMs.  They only depend on tensors that are
-        written once per layer, so they run beside the dX GEMM / LayerNorm / attention-backward
-        chain and fill the CUs those leave idle; the layer joins the two streams before returning."""
+        The four weight gradients are ONE grouped launch (dense_bwd_params_grouped), queued once
+        dqkv exists.  `side`: a second HIP stream for it: it then runs beside the last dX GEMM of
+        this layer and the start of the next one.  In that mode the dY buffers it reads are
+        double-buffered by layer parity and `self.dw_done` (an event on `side`) tells the caller
+        when the gradients are final and the buffers free (BertModel.backward waits on it two
+        layers later)."""
         cfg = self.cfg
         H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         x, mask, B, S, p_hid, p_att, seeds = self._stash
         T = B * S
         bb = self._bufs
-        acc = ops.GEMM_ACCUM_C if accumulate else 0
-        KS = ops.K_STRIDED
-        dz2, du = scratch("dz2", (T, H)), scratch("du", (T, I))
-        da1, dz1 = scratch("da1", (T, H)), scratch("dz1", (T, H))
-        dctx, dqkv = scratch("dctx", (T, H)), scratch("dqkv", (T, 3 * H))
+        par = "" if side is None else str(self.index & 1)
+        dz2, du = scratch("dz2" + par, (T, H)), scratch("du" + par, (T, I))
+        da1, dz1 = scratch("da1", (T, H)), scratch("dz1" + par, (T, H))
+        dctx, dqkv = scratch("dctx", (T, H)), scratch("dqkv" + par, (T, 3 * H))
         dx = scratch("dx%d" % (self.index & 1), (T, H))
-        main = torch.cuda.current_stream()
-        if side is not None and not hasattr(self, "_ev"):
-            self._ev = [torch.cuda.Event() for _ in range(5)]
-
-        def on_side(k, fn):
-            """Run fn on the side stream once everything queued so far on the main stream is done."""
-            if side is None:
-                return fn()
-            self._ev[k].record(main)
-            side.wait_event(self._ev[k])
-            with torch.cuda.stream(side):
-                fn()
         # z2 = dropout(ffn2(f)) + a1: the residual path takes dz2, the Dense path dz2 * mask/(1-p)
-        dz2m = scratch("dz2m", (T, H)) if p_hid > 0 else None
+        dz2m = scratch("dz2m" + par, (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(dy, bb["z2"], self.ln2_g.value, bb["m2"], bb["r2"], dz2,
                           self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate,
                           dx_masked=dz2m, drop_p=p_hid, seed=seeds[2])
         dz2d = dz2m if dz2m is not None else dz2
-        on_side(0, lambda: ops.gemm(dz2d, bb["f"], self.ffn2_w.grad, a_layout=KS, b_layout=KS, flags=acc,
-                                    split_k=dw_split_k(H, I, T)))
         gemm_dx(dz2d, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
-        on_side(1, lambda: ops.dense_bwd_params(du, bb["a1"], self.ffn1_w.grad, self.ffn1_b.grad, accumulate,
-                                                dw_split_k(I, H, T)))
         gemm_dx(du, self.ffn1_w, da1, resid=dz2)
-        dz1m = scratch("dz1m", (T, H)) if p_hid > 0 else None
+        dz1m = scratch("dz1m" + par, (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(da1, bb["z1"], self.ln1_g.value, bb["m1"], bb["r1"], dz1,
                           self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate,
                           dx_masked=dz1m, drop_p=p_hid, seed=seeds[1])
         dz1d = dz1m if dz1m is not None else dz1
-        on_side(2, lambda: ops.gemm(dz1d, bb["ctx"], self.out_w.grad, a_layout=KS, b_layout=KS, flags=acc,
-                                    split_k=dw_split_k(H, H, T)))
         gemm_dx(dz1d, self.out_w, dctx)
         ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A, drop_p=p_att, seed=seeds[0])
-        on_side(3, lambda: ops.dense_bwd_params(dqkv, x, self.qkv_w.grad, self.qkv_b.grad, accumulate,
-                                                dw_split_k(3 * H, H, T)))
+        problems = [(dz2d, bb["f"], self.ffn2_w.grad, None), (du, bb["a1"], self.ffn1_w.grad, self.ffn1_b.grad),
+                    (dz1d, bb["ctx"], self.out_w.grad, None), (dqkv, x, self.qkv_w.grad, self.qkv_b.grad)]
+        if side is None:
+            dense_bwd_params_group(problems, accumulate)
+            self.dw_done = None
+        else:
+            main = torch.cuda.current_stream()
+            if not hasattr(self, "_ev"):
+                self._ev = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev[0].record(main)
+            side.wait_event(self._ev[0])
+            with torch.cuda.stream(side):
+                dense_bwd_params_group(problems, accumulate)
+                self._ev[1].record(side)
+            self.dw_done = self._ev[1]
         gemm_dx(dqkv, self.qkv_w, dx, resid=dz1)
-        if side is not None:     # join: the next layer reuses dz2/du/dz1/dqkv, and the reducer may read the grads
-            self._ev[4].record(side)
-            main.wait_event(self._ev[4])
         return dx
 
 
@@ -439,9 +433,21 @@ class BertModel(PolusModel):
             dy = to_device(dy, self.compute_dtype, self.arena.device).reshape(B * S, -1)
         if self.overlap_dw and self._side is None:
             self._side = torch.cuda.Stream(device=self.arena.device)
+        side = self._side if self.overlap_dw else None
+        pending = []          # layers whose grouped dW launch is still running on the side stream
+        main = torch.cuda.current_stream()
+
+        def retire(lay):
+            if lay.dw_done is not None:
+                main.wait_event(lay.dw_done)
+            self._notify(lay.variables())
         for l in reversed(self.layer):
-            dy = l.backward(dy, self.scratch, accumulate, self._side if self.overlap_dw else None)
-            self._notify(l.variables())
+            if len(pending) == 2:      # this layer reuses the dY buffers of the layer two steps back
+                retire(pending.pop(0))
+            dy = l.backward(dy, self.scratch, accumulate, side)
+            pending.append(l)
+        for lay in pending:
+            retire(lay)
         if self.embeddings is not None:
             self.embeddings.backward(dy, accumulate, self.deterministic)
             self._notify(self.embeddings.variables())

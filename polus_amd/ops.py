@@ -289,6 +289,33 @@ def transpose_bf16(src, dst):
     check(_lib.load().polus_transpose_bf16(ptr(src), ptr(dst), R, C, _st()), "polus_transpose_bf16")
 
 
+def dense_bwd_params_grouped(problems, accumulate=False, split_k=1):
+    """dW (+ db) of several Dense layers in one launch.  problems: [(dy [T,n_out], x [T,n_in], dw f32 [n_out,n_in],
+    db f32 [n_out] or None), ...] with one common T."""
+    lib = _lib.load()
+    T = problems[0][0].shape[0]
+    arr = (_lib.DwProblem * len(problems))()
+    for k, (dy, x, dw, db) in enumerate(problems):
+        _req_cuda(dy, x, dw, db)
+        assert dy.dtype == x.dtype and dw.dtype == torch.float32 and dy.shape[0] == T and x.shape[0] == T
+        assert dy.stride(1) == 1 and x.stride(1) == 1 and dw.stride(1) == 1
+        n_out, n_in = dy.shape[1], x.shape[1]
+        assert tuple(dw.shape) == (n_out, n_in) and (db is None or (db.dtype == torch.float32 and db.numel() == n_out))
+        arr[k] = _lib.DwProblem(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(dw), dw.stride(0), ptr(db), n_out, n_in)
+    dt = dtype_code(problems[0][0].dtype)
+    nb = lib.polus_dense_bwd_params_grouped_workspace_bytes(len(problems), arr, T, int(split_k))
+    ws = workspace(problems[0][0].device).get(nb)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.polus_dense_bwd_params_grouped(dt, len(problems), arr, T, 1 if accumulate else 0, int(split_k),
+                                             ptr(ws), ws.numel(), _st()), "polus_dense_bwd_params_grouped")
+    if prof is not None:
+        e1.record()
+        prof.append(("dw", sum(2.0 * T * p[0].shape[1] * p[1].shape[1] for p in problems), e0, e1))
+
+
 def transpose_bf16_batched(src_base, dst_base, segs_dev, nseg, total_tiles):
     """All matrices of a flat bf16 arena into its transposed twin in one launch (segs: int64 [nseg, 4])."""
     _req_cuda(src_base, dst_base, segs_dev)

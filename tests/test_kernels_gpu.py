@@ -609,3 +609,34 @@ def test_gelu_polynomial_epilogue_precision(ops):
     ops.gemm(ones, eye, out, aux=x_t, act="gelu", flags=ops.GEMM_ACT_BWD)
     refg = ob.gelu_grad(xr)
     assert np.all(np.abs(host(out) - refg) <= 2.0 ** -8 * np.maximum(np.abs(refg), 2.0 ** -5))
+
+
+@pytest.mark.parametrize("T,split_k", [(4096, 1), (4096, 2), (1000, 3)])
+def test_dense_bwd_params_grouped(ops, T, split_k):
+    """All four weight gradients of an encoder layer in one launch: against dY^T X per matrix,
+    bitwise against the one-matrix entry point (same split), accumulate, and a null db."""
+    r = rng(T + split_k)
+    dt = torch.bfloat16
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    want_db = [False, True, False, True]
+    probs, refs = [], []
+    for (n_out, n_in), wb in zip(shapes, want_db):
+        dY, X = r.standard_normal((T, n_out)) * 0.1, r.standard_normal((T, n_in))
+        dw = torch.full((n_out, n_in), float("nan"), device="cuda")
+        db = torch.full((n_out,), float("nan"), device="cuda") if wb else None
+        probs.append((dev(dY, dt), dev(X, dt), dw, db))
+        refs.append((rounded(dY, dt).T @ rounded(X, dt), rounded(dY, dt).sum(0)))
+    ops.dense_bwd_params_grouped(probs, False, split_k)
+    for (dy, x, dw, db), (rw, rb) in zip(probs, refs):
+        assert_close(host(dw), rw, 2e-3, "grouped dW")
+        if db is not None:
+            assert_close(host(db), rb, 2e-3, "grouped db")
+            dw1, db1 = torch.empty_like(dw), torch.empty_like(db)
+            ops.dense_bwd_params(dy, x, dw1, db1, split_k=split_k)
+            assert torch.equal(dw, dw1) and torch.equal(db, db1), "grouped launch differs from the single-matrix one"
+    first = [(p[2].clone(), None if p[3] is None else p[3].clone()) for p in probs]
+    ops.dense_bwd_params_grouped(probs, True, split_k)
+    for (dy, x, dw, db), (w0, b0) in zip(probs, first):
+        assert_close(host(dw), 2 * host(w0), 1e-6, "grouped dW accumulate")
+        if db is not None:
+            assert_close(host(db), 2 * host(b0), 1e-6, "grouped db accumulate")
