@@ -30,13 +30,14 @@ template <> struct TileCfg<bf16_t> { static constexpr int RS = 160, EPC = 8, LOG
 template <> struct TileCfg<float> { static constexpr int RS = 288, EPC = 4, LOG_CPR = 4, NLOAD = 4; };
 
 // 64 x 64 tile: rows row0.. of a [*, ld] matrix at column offset col0 -> LDS (zero fill past nrows)
-template <typename T>
+// (NT threads load NT/4 rows: 64 rows for the 4-wave kernels, 16*NW for the wide ones)
+template <typename T, int NT = 256>
 __device__ __forceinline__ void tile_load(unsigned char* tile, const T* __restrict__ base, long ld, int row0,
                                           int nrows, int col0, int tid) {
     constexpr int LOG = TileCfg<T>::LOG_CPR;
 #pragma unroll
     for (int k = 0; k < TileCfg<T>::NLOAD; ++k) {
-        int c = tid + 256 * k;
+        int c = tid + NT * k;
         int r = c >> LOG, ch = c & ((1 << LOG) - 1);
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row0 + r < nrows)
@@ -123,14 +124,18 @@ __device__ __forceinline__ float key_bias(const int32_t* mask, int b, int S, int
 }
 
 // ---------------------------------------------------------------- forward
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + BLK * 4];
-    unsigned char* Kt = smem;
-    unsigned char* Vt = smem + BLK * TileCfg<T>::RS;
-    float* kbias = reinterpret_cast<float*>(smem + 2 * BLK * TileCfg<T>::RS);
+// NW waves per workgroup: 16*NW queries, and K / V are staged 16*NW keys at a time -- with NW = 16
+// the whole key range of a 256-token sequence sits in LDS after ONE load + barrier pair (the
+// 4-wave form pays a global-load latency and two barriers per 64 keys, which is what bounds it).
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int QB = 16 * NW, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kc = smem;
+    unsigned char* Vc = smem + QB * TileCfg<T>::RS;
+    float* kbc = reinterpret_cast<float*>(smem + 2 * QB * TileCfg<T>::RS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * BLK, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
     const int S = p.S, H = p.H;
     const long ld = 3L * H;
     const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
@@ -148,12 +153,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kb0 = 0; kb0 < S; kb0 += BLK) {
+    for (int kc0 = 0; kc0 < S; kc0 += QB) {
         __syncthreads();
-        tile_load<T>(Kt, qkv, ld, kb0, S, H + h * D, tid);
-        tile_load<T>(Vt, qkv, ld, kb0, S, 2 * H + h * D, tid);
-        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid) * LOG2E;
+        tile_load<T, NT>(Kc, qkv, ld, kc0, S, H + h * D, tid);
+        tile_load<T, NT>(Vc, qkv, ld, kc0, S, 2 * H + h * D, tid);
+        if (tid < QB) kbc[tid] = key_bias(p.mask, b, S, kc0 + tid) * LOG2E;
         __syncthreads();
+      for (int kb0 = kc0; kb0 < kc0 + QB && kb0 < S; kb0 += BLK) {
+        const unsigned char* Kt = Kc + (kb0 - kc0) * TileCfg<T>::RS;
+        const unsigned char* Vt = Vc + (kb0 - kc0) * TileCfg<T>::RS;
+        const float* kbias = kbc + (kb0 - kc0);
 
         f32x4 s[4];
 #pragma unroll
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 mma16(o[dt], va, pb);  // D[d 4g+r][query i]
             }
         }
+      }
     }
     T* ctx = static_cast<T*>(p.ctx) + (long)b * S * H;
     store_acc_T<T>(ctx, H, q, h * D, o, 1.0f / l, g, qvalid);
@@ -236,14 +246,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ---------------------------------------------------------------- dQ
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + BLK * 4];
-    unsigned char* Kt = smem;
-    unsigned char* Vt = smem + BLK * TileCfg<T>::RS;
-    float* kbias = reinterpret_cast<float*>(smem + 2 * BLK * TileCfg<T>::RS);
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
+    constexpr int QB = 16 * NW, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kc = smem;
+    unsigned char* Vc = smem + QB * TileCfg<T>::RS;
+    float* kbc = reinterpret_cast<float*>(smem + 2 * QB * TileCfg<T>::RS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * BLK, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
     const int S = p.S, H = p.H;
     const long ld = 3L * H;
     const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
@@ -266,12 +277,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kb0 = 0; kb0 < S; kb0 += BLK) {
+    for (int kc0 = 0; kc0 < S; kc0 += QB) {
         __syncthreads();
-        tile_load<T>(Kt, qkv, ld, kb0, S, H + h * D, tid);
-        tile_load<T>(Vt, qkv, ld, kb0, S, 2 * H + h * D, tid);
-        if (tid < BLK) kbias[tid] = key_bias(p.mask, b, S, kb0 + tid) * LOG2E;
+        tile_load<T, NT>(Kc, qkv, ld, kc0, S, H + h * D, tid);
+        tile_load<T, NT>(Vc, qkv, ld, kc0, S, 2 * H + h * D, tid);
+        if (tid < QB) kbc[tid] = key_bias(p.mask, b, S, kc0 + tid) * LOG2E;
         __syncthreads();
+      for (int kb0 = kc0; kb0 < kc0 + QB && kb0 < S; kb0 += BLK) {
+        const unsigned char* Kt = Kc + (kb0 - kc0) * TileCfg<T>::RS;
+        const unsigned char* Vt = Vc + (kb0 - kc0) * TileCfg<T>::RS;
+        const float* kbias = kbc + (kb0 - kc0);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -309,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
                 mma16(dq[dt], ka, dsb);  // D[d][query]
             }
         }
+      }
     }
     T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
     store_acc_T<T>(dqkv, ld, q, h * D, dq, 1.0f, g, qvalid);
@@ -412,6 +428,36 @@ int check_common(const char* who, int dtype, int B, int S, int A, int hd) {
 
 }  // namespace
 
+namespace {
+// Forward (WHICH = 0) and dQ (WHICH = 1) kernels: waves per workgroup by sequence length.  bf16:
+// 8 waves (128 keys staged per load + barrier pair) from S >= 96, else 4; 16 waves (a whole
+// 256-token sequence resident, 83 KiB) measures the same as 8 and is reachable with
+// POLUS_ATTN_WAVES=16; f32 (288-byte rows, more registers): always 4.
+template <int WHICH, typename T, int NW>
+int launch_wide_nw(const AttnArgs& a, hipStream_t st) {
+    auto kern = WHICH == 0 ? attn_fwd_kernel<T, NW> : attn_bwd_dq_kernel<T, NW>;
+    constexpr int QB = 16 * NW;
+    const size_t lds = 2 * (size_t)QB * TileCfg<T>::RS + QB * 4;
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid((a.S + QB - 1) / QB, a.A, a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
+    return POLUS_OK;
+}
+template <int WHICH>
+int launch_wide(int dtype, const AttnArgs& a, hipStream_t st) {
+    if (dtype != POLUS_BF16) return launch_wide_nw<WHICH, float, 4>(a, st);
+    const char* e = getenv("POLUS_ATTN_WAVES");
+    int nw = e ? atoi(e) : (a.S >= 96 ? 8 : 4);
+    if (nw >= 16) return launch_wide_nw<WHICH, bf16_t, 16>(a, st);
+    if (nw >= 8) return launch_wide_nw<WHICH, bf16_t, 8>(a, st);
+    return launch_wide_nw<WHICH, bf16_t, 4>(a, st);
+}
+}  // namespace
+
 extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* mask, void* ctx, float* lse,
                                    int B, int S, int n_heads, int head_dim, float drop_p, uint32_t seed, void* stream) {
     int rc = check_common("polus_attention_fwd", dtype, B, S, n_heads, head_dim);
@@ -423,10 +469,9 @@ extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* ma
     a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.lse = lse;
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
     a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p);
-    dim3 grid((S + BLK - 1) / BLK, n_heads, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == POLUS_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, st, a);
+    int rc2 = launch_wide<0>(dtype, a, st);
+    if (rc2 != POLUS_OK) return rc2;
     POLUS_CHECK_LAUNCH("polus_attention_fwd");
     return POLUS_OK;
 }
@@ -459,13 +504,13 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
     if (dtype == POLUS_BF16) {
         hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(dblocks), dim3(256), 0, st, (const bf16_t*)ctx, (const bf16_t*)dctx, static_cast<float*>(workspace), B, S, n_heads, a.H);
         POLUS_CHECK_LAUNCH("polus_attention_bwd(delta)");
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+        { int rc2 = launch_wide<1>(dtype, a, st); if (rc2 != POLUS_OK) return rc2; }
         POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dblocks), dim3(256), 0, st, (const float*)ctx, (const float*)dctx, static_cast<float*>(workspace), B, S, n_heads, a.H);
         POLUS_CHECK_LAUNCH("polus_attention_bwd(delta)");
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, grid, dim3(256), 0, st, a);
+        { int rc2 = launch_wide<1>(dtype, a, st); if (rc2 != POLUS_OK) return rc2; }
         POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), 0, st, a);
     }
