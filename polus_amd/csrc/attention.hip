@@ -225,26 +225,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
     if (qvalid && g == 0) p.lse[((long)b * p.A + h) * S + q] = m * LN2 + __logf(l);
 }
 
-// ---------------------------------------------------------------- delta = rowsum(dO * O) per head
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int S, int A, int H) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int rows = B * S;
-    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
-        const int b = row / S, s = row % S;
-        for (int col = lane * 4; col < H; col += 256) {
-            float a[4], c[4];
-            load4<T>(o + (long)row * H + col, a);
-            load4<T>(dout + (long)row * H + col, c);
-            float v = a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
-            // 16 consecutive lanes cover one head (64 features)
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if ((lane & 15) == 0) delta[((long)b * A + col / D) * S + s] = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------- dQ
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -271,7 +251,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
     const long stat = ((long)b * p.A + h) * S + q;
     const float lse2 = (qvalid ? p.lse[stat] : 0.f) * LOG2E;
     const float scale2 = p.scale * LOG2E;
-    const float dl = qvalid ? p.delta[stat] : 0.f;
+    // delta = rowsum(dO * O) of this query's head (softmax backward); computed here from the dO
+    // fragments the lane already holds and published for the dK/dV kernel that runs next
+    float dl = 0.f;
+    {
+        const T* ctx = static_cast<const T*>(p.ctx) + (long)b * S * H;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            Frag<T> of;
+            frag_global<T>(of, ctx + (long)q * H + h * D + sub * 32 + 8 * g, qvalid);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of.v[j] * (float)dof[sub].v[j];
+        }
+        dl = col_sum(dl);
+        if (qvalid && g == 0) const_cast<float*>(p.delta)[stat] = dl;
+    }
 
     f32x4 dq[4];
 #pragma unroll
@@ -492,24 +486,18 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
     size_t need = polus_attention_bwd_workspace_bytes(B, S, n_heads);
     if (!workspace || workspace_bytes < need) { polus_set_error("polus_attention_bwd: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
     AttnArgs a = {};
-    a.qkv = qkv; a.mask = mask; a.lse = const_cast<float*>(lse); a.dctx = dctx; a.dqkv = dqkv;
+    a.qkv = qkv; a.mask = mask; a.ctx = const_cast<void*>(ctx); a.lse = const_cast<float*>(lse); a.dctx = dctx; a.dqkv = dqkv;
     a.delta = static_cast<const float*>(workspace);
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
     POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "polus_attention_bwd: bad drop_p");
     a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rows = B * S, dblocks = (rows + 3) / 4;
-    if (dblocks > 4096) dblocks = 4096;
     dim3 grid((S + BLK - 1) / BLK, n_heads, B);
     if (dtype == POLUS_BF16) {
-        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(dblocks), dim3(256), 0, st, (const bf16_t*)ctx, (const bf16_t*)dctx, static_cast<float*>(workspace), B, S, n_heads, a.H);
-        POLUS_CHECK_LAUNCH("polus_attention_bwd(delta)");
         { int rc2 = launch_wide<1>(dtype, a, st); if (rc2 != POLUS_OK) return rc2; }
         POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dblocks), dim3(256), 0, st, (const float*)ctx, (const float*)dctx, static_cast<float*>(workspace), B, S, n_heads, a.H);
-        POLUS_CHECK_LAUNCH("polus_attention_bwd(delta)");
         { int rc2 = launch_wide<1>(dtype, a, st); if (rc2 != POLUS_OK) return rc2; }
         POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, grid, dim3(256), 0, st, a);

@@ -109,6 +109,30 @@ __global__ __launch_bounds__(256) void transpose16_batched_kernel(const unsigned
     const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
     const unsigned short* sp = src + off;
     unsigned short* dp = dst + off;
+    if (((R | C) & 3) == 0) {
+        // 8-byte accesses: thread t reads 4 consecutive columns of row t/16 (+16 per pass), writes 4
+        // consecutive rows of output row t/16 (+16 per pass); arena offsets are 64-element aligned
+        const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + rr + 16 * k, c = c0 + 4 * q;
+            ushort4 v = make_ushort4(0, 0, 0, 0);
+            if (r < R && c < C) v = *reinterpret_cast<const ushort4*>(sp + (long)r * C + c);
+            tile[rr + 16 * k][4 * q] = v.x; tile[rr + 16 * k][4 * q + 1] = v.y;
+            tile[rr + 16 * k][4 * q + 2] = v.z; tile[rr + 16 * k][4 * q + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + rr + 16 * k, r = r0 + 4 * q;
+            if (c < C && r < R) {
+                ushort4 v = make_ushort4(tile[4 * q][rr + 16 * k], tile[4 * q + 1][rr + 16 * k],
+                                         tile[4 * q + 2][rr + 16 * k], tile[4 * q + 3][rr + 16 * k]);
+                *reinterpret_cast<ushort4*>(dp + (long)c * R + r) = v;
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int k = ty; k < 64; k += 4) {
         int r = r0 + k, c = c0 + tx;
