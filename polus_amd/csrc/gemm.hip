@@ -271,13 +271,14 @@ static int polus_num_cus() {
     return n;
 }
 // The persistent 256x192 kernel (gemm_p.hip): higher FLOP per filled byte than the ring kernel, but
-// with one wave per SIMD nothing overlaps its epilogue, so it only wins where a tile has little to
-// write per FLOP (N <= K: attention-out and FFN2 forward, +9 %) and the epilogue has no second
-// store or load stream.  Needs K % 64 == 0, N % 192 == 0 and (nearly) full rounds of #CU tiles.
+// with one wave per SIMD nothing overlaps its epilogue.  It was 9 % ahead on the N <= K shapes until
+// the ring kernel got compile-time epilogue modes too; now the two tie in the training step
+// (4010 vs 4024 samples/s), so it is opt-in: POLUS_GEMM_P=1 uses it where a tile has little to
+// write per FLOP (N <= K, no second store or load stream), POLUS_GEMM_P=2 wherever it is legal
+// (tests).  Needs K % 64 == 0, N % 192 == 0 and (nearly) full rounds of #CU tiles.
 static bool use_persistent(int M, int N, int K, int mode) {
-    // POLUS_GEMM_P: 0 = never, 1 = where it wins (default), 2 = whenever legal (tests)
     const char* e = getenv("POLUS_GEMM_P");
-    const int sel = e ? atoi(e) : 1;
+    const int sel = e ? atoi(e) : 0;
     if (sel == 0 || mode < 0 || K % 64 != 0 || M < 256 || N < 192) return false;
     if (sel == 2) return true;
     if (!(mode == 0 || mode == 2) || N > K || (N % 192) != 0) return false;

@@ -205,6 +205,147 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Shared by gemm_p.hip and (K-contiguous operands, bf16 C) gemm_ring.hip.
+template <int WN> struct EpiCfg {
+    static constexpr int RS = WN * 4 + 16;            // staging row stride (f32 row of the wave + pad)
+    static constexpr int BYTES = 9 * RS;              // half an m-tile (8 rows) + one dump row
+    static constexpr int SLOTS = 8 * (WN / 8);        // 8 rows x eight-column chunks, one per lane
+    static constexpr int PASSES = (SLOTS + 63) / 64;
+};
+// Pins the point where an accumulator tile is read: the copy out of the accumulator registers
+// cannot be hoisted above this (otherwise all copies pile up at the top of the epilogue and spill).
+template <bool AGPR> __device__ __forceinline__ f32x4 acc_take(f32x4& acc) {
+    if (AGPR) asm volatile("" : "+a"(acc) :: "memory");
+    else asm volatile("" : "+v"(acc) :: "memory");
+    return acc;
+}
+// ---------------------------------------------------------------------------------------------
+// Epilogue of one wave: 128 rows x WN columns, one 16-row m-tile at a time through a
+// wave-private f32 staging buffer so that global accesses are 16 B per lane on whole rows.
+// Same operation order as pgemm::epilogue_tile.
+// MODE (compile time, so that variants without loads carry no vmcnt waits between their stores --
+// vmcnt retires in order, a wait for a residual load would also wait for every older C store):
+//   0 = alpha/bias only, 1 = ACT_FWD (+ pre-activation to aux), 2 = residual (+ dropout), 3 = ACT_BWD (aux read)
+// AGPR: the accumulators are pinned to AGPRs by inline-asm MFMAs (gemm_p.hip) or live in VGPRs (gemm_ring.hip).
+template <typename TC, int WN, bool DROP, int MODE, bool AGPR>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8][WN / 16], int mb, int nb,
+                                              int lane, unsigned char* lds) {
+    typedef bf16_t T;
+    constexpr int NT = WN / 16, RS = EpiCfg<WN>::RS, PASSES = EpiCfg<WN>::PASSES, CPR = 2 * NT;  // 8-col chunks per row
+    const int i = lane & 15, g = lane >> 4;
+    const bool interior = p.epi_vec16 && (mb + 128 <= p.M) && (nb + WN <= p.N);
+    if (!interior) {
+#pragma clang loop unroll(full)
+        for (int mt = 0; mt < 8; ++mt)
+#pragma clang loop unroll(full)
+            for (int nt = 0; nt < NT; ++nt)
+                epilogue_tile<T, TC, DROP>(p, acc_take<AGPR>(acc[mt][nt]), mb + mt * 16 + i, nb + nt * 16 + 4 * g, 0);
+        return;
+    }
+    constexpr bool act_fwd = MODE == 1, act_bwd = MODE == 3, accum = false, has_resid = MODE == 2;
+    const T* resid = static_cast<const T*>(p.resid);
+    T* aux = static_cast<T*>(p.aux);
+    TC* C = static_cast<TC*>(p.C);
+    constexpr int SLOTS = EpiCfg<WN>::SLOTS;
+    int prow[PASSES], pcol[PASSES];
+    float bv[PASSES][8];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        int slot = ps * 64 + lane;
+        if (slot >= SLOTS) slot = 0;
+        prow[ps] = slot / CPR;
+        pcol[ps] = 8 * (slot % CPR);
+        if (p.bias) {
+            load4<float>(p.bias + nb + pcol[ps], *reinterpret_cast<float(*)[4]>(&bv[ps][0]));
+            load4<float>(p.bias + nb + pcol[ps] + 4, *reinterpret_cast<float(*)[4]>(&bv[ps][4]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bv[ps][r] = 0.f;
+        }
+    }
+    // residual / aux rows are fetched one m-tile ahead, so the (in-order) wait for them only has
+    // to get past the previous m-tile's stores' *issue*, never their completion
+    bf16x8_t pre[2][2][PASSES];
+    auto fetch = [&](int mt, bf16x8_t (&dst)[2][PASSES]) {
+        const T* base = has_resid ? resid : static_cast<const T*>(aux);
+        const long ld = has_resid ? p.ldr : p.ldaux;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps)
+                dst[h][ps] = *reinterpret_cast<const bf16x8_t*>(base + (long)(mb + mt * 16 + h * 8 + prow[ps]) * ld + nb + pcol[ps]);
+    };
+    if (has_resid || act_bwd) fetch(0, pre[0]);
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < 8; ++mt) {
+        f32x4 t[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t[nt] = acc_take<AGPR>(acc[mt][nt]);
+        if ((has_resid || act_bwd) && mt < 7) fetch(mt + 1, pre[(mt + 1) & 1]);
+#pragma clang loop unroll(full)
+        for (int h = 0; h < 2; ++h) {
+            // rows 8h..8h+7 of the m-tile live in lanes with (i>>3) == h; the other lanes write to a
+            // dump row instead of being masked off (hipcc 7.2 sinks the following reads and their
+            // math into a divergent `if` here, leaving the masked-off lanes with stale registers)
+            {
+                unsigned char* wrow = lds + (((i >> 3) == h) ? (i & 7) : 8) * RS;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    *reinterpret_cast<f32x4*>(wrow + (nt * 16 + 4 * g) * 4) = t[nt];
+            }
+#pragma clang loop unroll(full)
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const bool live = !(ps * 64 + 64 > SLOTS) || (ps * 64 + lane < SLOTS);
+                const long m = mb + mt * 16 + h * 8 + prow[ps];
+                const int ncol = nb + pcol[ps];
+                const unsigned char* src = lds + prow[ps] * RS + pcol[ps] * 4;
+                f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bv[ps][r];
+                if (act_fwd) {
+                    if (aux && live) {
+                        bf16x8_t tt;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol) = tt;
+                    }
+                    apply_act_n<8, true>(p.act, v);
+                }
+                if (act_bwd) {
+                    float u[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) u[r] = (float)pre[mt & 1][h][ps][r];
+                    apply_act_grad_n<8, true>(p.act, v, u);
+                }
+                if (DROP) {
+                    const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
+                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 1) == 0);
+                }
+                if (has_resid) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)pre[mt & 1][h][ps][r];
+                }
+                if (live) {
+                    if (sizeof(TC) == 4) {
+                        float* dst = reinterpret_cast<float*>(C) + m * p.ldc + ncol;
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        bf16x8_t tt;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
+                        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<T*>(C) + m * p.ldc + ncol) = tt;
+                    }
+                }
+            }
+        }
+    }
+}
+
+
 // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
 // contiguous run of tiles so that neighbours reuse the same A row panel.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

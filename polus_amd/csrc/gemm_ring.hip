@@ -49,7 +49,9 @@ __device__ __forceinline__ int pi4(int q) { return (0x78 >> (2 * q)) & 3; }
 #define POLUS_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // One 256x128 output tile (workgroup `wg` of the `nwg` that cover the problem) of K-split `split`.
-template <typename TC, bool A_KS, bool B_KS, bool DROP>
+// MODE >= 0 (bf16 C, both operands K-contiguous): epilogue variant fixed at compile time
+// (pgemm::epilogue_wave); MODE = -1: the run-time epilogue (f32 C, split-K slabs, K-strided operands).
+template <typename TC, bool A_KS, bool B_KS, bool DROP, int MODE = -1>
 __device__ __forceinline__ void ring_body(const GemmArgs& p, const int wg_in, const int nwg, const int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -207,12 +209,13 @@ __device__ __forceinline__ void ring_body(const GemmArgs& p, const int wg_in, co
     }
     GemmArgs q = p;
     q.C = static_cast<TC*>(p.C) + (long)split * p.c_split_stride;
-    epilogue_wave_128x64_lds<TC, DROP>(q, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    if (MODE >= 0) epilogue_wave<TC, 64, DROP, MODE < 0 ? 0 : MODE, false>(q, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    else epilogue_wave_128x64_lds<TC, DROP>(q, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
-template <typename TC, bool A_KS, bool B_KS, bool DROP>
+template <typename TC, bool A_KS, bool B_KS, bool DROP, int MODE = -1>
 __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
-    ring_body<TC, A_KS, B_KS, DROP>(p, blockIdx.x, gridDim.x, blockIdx.y);
+    ring_body<TC, A_KS, B_KS, DROP, MODE>(p, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // Several problems with the same contraction length in one launch (the dW = dY^T X of all four
@@ -257,10 +260,10 @@ typedef __attribute__((address_space(1))) void gvoid_t;
     ring_body<TC, A_KS, B_KS, false>(P, wg, ga.tiles[q], blockIdx.y);
 }
 
-template <typename TC, bool A_KS, bool B_KS, bool DROP = false>
+template <typename TC, bool A_KS, bool B_KS, bool DROP = false, int MODE = -1>
 int launch_ring(const GemmArgs& a, int splits, hipStream_t st) {
     static bool attr_done = false;
-    auto kern = gemm_ring_kernel<TC, A_KS, B_KS, DROP>;
+    auto kern = gemm_ring_kernel<TC, A_KS, B_KS, DROP, MODE>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
@@ -307,9 +310,19 @@ int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, int splits, 
 }
 
 int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
+    if (polus_gemm_p_mode(a, 0, 1) == 2 && !getenv("POLUS_RING_RUNTIME_EPI")) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
     return launch_ring<bf16_t, false, false, true>(a, 1, st);
 }
 
 int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st) {
+    if (!c_is_f32 && !a_ks && !b_ks && splits == 1 && !getenv("POLUS_RING_RUNTIME_EPI")) {
+        switch (polus_gemm_p_mode(a, 0, 0)) {      // same epilogue classes as the persistent kernel
+            case 0: return launch_ring<bf16_t, false, false, false, 0>(a, 1, st);
+            case 1: return launch_ring<bf16_t, false, false, false, 1>(a, 1, st);
+            case 2: return launch_ring<bf16_t, false, false, false, 2>(a, 1, st);
+            case 3: return launch_ring<bf16_t, false, false, false, 3>(a, 1, st);
+            default: break;
+        }
+    }
     return c_is_f32 ? launch_layout<float>(a, a_ks, b_ks, splits, st) : launch_layout<bf16_t>(a, a_ks, b_ks, splits, st);
 }
