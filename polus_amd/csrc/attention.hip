@@ -327,11 +327,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
 // ---------------------------------------------------------------- dK, dV
 template <typename T>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kernel(AttnArgs p) {   // bf16: 3 waves per SIMD (<= 168 registers)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BLK * TileCfg<T>::RS + 2 * BLK * 4];
-    unsigned char* Qt = smem;
-    unsigned char* Ot = smem + BLK * TileCfg<T>::RS;
-    float* slse = reinterpret_cast<float*>(smem + 2 * BLK * TileCfg<T>::RS);
-    float* sdelta = slse + BLK;
+    // Q and dO are staged QCH query rows per load + barrier pair (bf16: 128, i.e. two 64-row blocks)
+    constexpr int QCH = sizeof(T) == 2 ? 2 * BLK : BLK;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QCH * TileCfg<T>::RS + 2 * QCH * 4];
+    unsigned char* Qc = smem;
+    unsigned char* Oc = smem + QCH * TileCfg<T>::RS;
+    float* lsec = reinterpret_cast<float*>(smem + 2 * QCH * TileCfg<T>::RS);
+    float* deltac = lsec + QCH;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
     const int k0 = blockIdx.x * BLK, h = blockIdx.y, b = blockIdx.z;
     const int S = p.S, H = p.H;
@@ -354,16 +356,24 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kern
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    for (int qb0 = 0; qb0 < S; qb0 += BLK) {
+    for (int qc0 = 0; qc0 < S; qc0 += QCH) {
         __syncthreads();
-        tile_load<T>(Qt, qkv, ld, qb0, S, h * D, tid);
-        tile_load<T>(Ot, dctx, H, qb0, S, h * D, tid);
-        if (tid < BLK) {
-            int qq = qb0 + tid;
-            slse[tid] = qq < S ? p.lse[stat0 + qq] * LOG2E : INFINITY;  // exp2(-inf) = 0 for padded queries
-            sdelta[tid] = qq < S ? p.delta[stat0 + qq] : 0.f;
+#pragma unroll
+        for (int part = 0; part < QCH / BLK; ++part) {
+            tile_load<T>(Qc + part * BLK * TileCfg<T>::RS, qkv, ld, qc0 + part * BLK, S, h * D, tid);
+            tile_load<T>(Oc + part * BLK * TileCfg<T>::RS, dctx, H, qc0 + part * BLK, S, h * D, tid);
+        }
+        if (tid < QCH) {
+            int qq = qc0 + tid;
+            lsec[tid] = qq < S ? p.lse[stat0 + qq] * LOG2E : INFINITY;  // exp2(-inf) = 0 for padded queries
+            deltac[tid] = qq < S ? p.delta[stat0 + qq] : 0.f;
         }
         __syncthreads();
+      for (int qb0 = qc0; qb0 < qc0 + QCH && qb0 < S; qb0 += BLK) {
+        const unsigned char* Qt = Qc + (qb0 - qc0) * TileCfg<T>::RS;
+        const unsigned char* Ot = Oc + (qb0 - qc0) * TileCfg<T>::RS;
+        const float* slse = lsec + (qb0 - qc0);
+        const float* sdelta = deltac + (qb0 - qc0);
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
@@ -406,6 +416,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kern
                 mma16(dk[dt], a, dsb);  // dK^T[d][key] += Q^T dS
             }
         }
+      }
     }
     T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
     store_acc_T<T>(dqkv, ld, key, H + h * D, dk, 1.0f, g, kvalid);

@@ -310,7 +310,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
                         bf16x8_t tt;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
-                        *reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol) = tt;
+                        // the pre-activation is only read again in the backward pass: streaming store
+                        __builtin_nontemporal_store(tt, reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol));
                     }
                     apply_act_n<8, true>(p.act, v);
                 }
