@@ -98,8 +98,9 @@ int polus_dense_bwd_params(int dtype, const void* dY, long lddy, const void* X, 
 /* The same for up to POLUS_MAX_GROUP (8) Dense layers in ONE launch -- the four weight gradients of
  * an encoder layer (the per-variable MatMul grads tape.gradient emits for one TFBertLayer,
  * polus/training.py:185 through polus/models.py:205-213): the concatenated tile lists fill the chip
- * with 1-2 K-splits instead of 7-28 per matrix.  All problems share T, `accumulate` and `split_k`;
- * db may be NULL per problem.  Falls back to one call per problem when a shape does not fit the
+ * with 2-3 K-splits instead of 7-28 per matrix.  All problems share T and `accumulate`; split_k > 0
+ * applies to every problem, split_k <= 0 lets the library choose per problem so that the launch is
+ * one full round of workgroup slots; db may be NULL per problem.  Falls back to one call per problem when a shape does not fit the
  * grouped kernel. */
 typedef struct polus_dw_problem {
     const void* dY; long lddy;     /* [T, n_out] */

@@ -515,27 +515,64 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
 }
 
 // ---- The same for several Dense layers at once (all four of an encoder layer): one ring launch
-// over the concatenated tile lists, so the chip fills with 1-2 K-splits instead of 7-28 per matrix
-// (each split is an f32 slab written and read back).  All problems share T, accumulate and split_k.
-static size_t grouped_need(int n, const polus_dw_problem* pr, int split_k, size_t* slab_off, size_t* cs_off) {
+// over the concatenated (split, tile) lists, so the chip fills with 2-3 K-splits instead of 7-28 per
+// matrix (each split is an f32 slab written and read back).  All problems share T and accumulate.
+// split_k > 0: that many splits for every problem; split_k <= 0: chosen per problem so that the
+// launch is one full round of the 2 x #CU workgroup slots.
+static void grouped_splits(int n, const polus_dw_problem* pr, int T, int split_k, int* splits) {
+    const int nkt = (T + 63) / 64;
+    int tiles[POLUS_MAX_GROUP], total = 0;
+    for (int k = 0; k < n; ++k) {
+        tiles[k] = ((pr[k].n_out + 255) / 256) * ((pr[k].n_in + 127) / 128);
+        total += tiles[k];
+    }
+    if (split_k > 0) {
+        for (int k = 0; k < n; ++k) splits[k] = split_k < nkt ? split_k : nkt;
+        return;
+    }
+    // Workgroups go to the 8 XCDs round-robin and each tile list is padded to a multiple of 8, so
+    // XCD 0 receives ceil(tiles/8) workgroups of every (problem, split).  All workgroups run for
+    // about the same (long) time: one more than 2 x CUs-per-XCD on any XCD doubles the kernel.
+    const int slots_xcd = 2 * polus_num_cus() / 8;
+    int per_xcd[POLUS_MAX_GROUP], total_xcd = 0;
+    for (int k = 0; k < n; ++k) { per_xcd[k] = (tiles[k] + 7) / 8; total_xcd += per_xcd[k]; }
+    int base = slots_xcd / (total_xcd > 0 ? total_xcd : 1);
+    if (base < 1) base = 1;
+    const int cap = nkt / 4 > 0 ? nkt / 4 : 1;          // >= 256 contraction rows per split
+    if (base > cap) base = cap;
+    int used = 0;
+    for (int k = 0; k < n; ++k) { splits[k] = base; used += per_xcd[k] * base; }
+    // hand the remaining slots to the problems with the most tiles that still fit, one extra split each
+    bool given[POLUS_MAX_GROUP] = {false};
+    for (;;) {
+        int best = -1;
+        for (int k = 0; k < n; ++k)
+            if (!given[k] && splits[k] < cap && used + per_xcd[k] <= slots_xcd && (best < 0 || tiles[k] > tiles[best])) best = k;
+        if (best < 0) break;
+        given[best] = true; ++splits[best]; used += per_xcd[best];
+    }
+}
+
+static size_t grouped_need(int n, const polus_dw_problem* pr, const int* splits, size_t* slab_off, size_t* cs_off) {
     size_t off = 0;
     for (int k = 0; k < n; ++k) {
         slab_off[k] = off;
-        if (split_k > 1) off += (((size_t)split_k * pr[k].n_out * pr[k].n_in * sizeof(float) + 255) / 256) * 256;
+        if (splits[k] > 1) off += (((size_t)splits[k] * pr[k].n_out * pr[k].n_in * sizeof(float) + 255) / 256) * 256;
         cs_off[k] = off;
-        off += (((size_t)split_k * pr[k].n_out * sizeof(float) + 255) / 256) * 256;
+        off += (((size_t)splits[k] * pr[k].n_out * sizeof(float) + 255) / 256) * 256;
     }
     return off + 256;
 }
 
 extern "C" size_t polus_dense_bwd_params_grouped_workspace_bytes(int n, const polus_dw_problem* problems, int T, int split_k) {
-    if (n < 1 || n > POLUS_MAX_GROUP || !problems) return 0;
-    if (split_k < 1) split_k = 1;
+    if (n < 1 || n > POLUS_MAX_GROUP || !problems || T < 1) return 0;
+    int splits[POLUS_MAX_GROUP];
+    grouped_splits(n, problems, T, split_k, splits);
     size_t so[POLUS_MAX_GROUP], co[POLUS_MAX_GROUP];
-    size_t grouped = grouped_need(n, problems, split_k, so, co);
+    size_t grouped = grouped_need(n, problems, splits, so, co);
     size_t single = 0;   // fallback path runs them one by one
     for (int k = 0; k < n; ++k) {
-        size_t b = polus_dense_bwd_params_workspace_bytes(T, problems[k].n_out, problems[k].n_in, split_k);
+        size_t b = polus_dense_bwd_params_workspace_bytes(T, problems[k].n_out, problems[k].n_in, splits[k]);
         if (b > single) single = b;
     }
     return grouped > single ? grouped : single;
@@ -544,7 +581,6 @@ extern "C" size_t polus_dense_bwd_params_grouped_workspace_bytes(int n, const po
 extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_problem* problems, int T, int accumulate,
                                               int split_k, void* workspace, size_t workspace_bytes, void* stream) {
     POLUS_REQUIRE(problems && n >= 1 && n <= POLUS_MAX_GROUP && T > 0, "polus_dense_bwd_params_grouped: bad arguments");
-    if (split_k < 1) split_k = 1;
     const size_t es = polus_dtype_size(dtype);
     bool ring = dtype == POLUS_BF16 && !getenv("POLUS_GEMM_V1") && !getenv("POLUS_DW_UNGROUPED");
     for (int k = 0; k < n; ++k) {
@@ -553,6 +589,8 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         ring = ring && polus_aligned16(q.dY) && polus_aligned16(q.X) && ((q.lddy * es) % 16 == 0) && ((q.ldx * es) % 16 == 0) &&
                (q.n_out % 8 == 0) && (q.n_in % 8 == 0) && q.n_out >= 256 && q.n_in >= 128;
     }
+    int splits[POLUS_MAX_GROUP];
+    grouped_splits(n, problems, T, split_k, splits);
     size_t need = polus_dense_bwd_params_grouped_workspace_bytes(n, problems, T, split_k);
     if (!workspace || workspace_bytes < need) { polus_set_error("polus_dense_bwd_params_grouped: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
     if (!ring) {
@@ -560,10 +598,10 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
             const polus_dw_problem& q = problems[k];
             int rc;
             if (q.db) rc = polus_dense_bwd_params(dtype, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw, q.db, T, q.n_out, q.n_in,
-                                                  accumulate, split_k, workspace, workspace_bytes, stream);
+                                                  accumulate, splits[k], workspace, workspace_bytes, stream);
             else rc = polus_gemm(dtype, POLUS_K_STRIDED, POLUS_K_STRIDED, POLUS_F32, q.dY, q.lddy, q.X, q.ldx, q.dW, q.lddw,
                                  q.n_out, q.n_in, T, 1.0f, nullptr, nullptr, 0, nullptr, 0, 0, accumulate ? POLUS_GEMM_ACCUM_C : 0,
-                                 split_k, workspace, workspace_bytes, stream);
+                                 splits[k], workspace, workspace_bytes, stream);
             if (rc != POLUS_OK) return rc;
         }
         return POLUS_OK;
@@ -571,11 +609,14 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int bk = 64;
     const int nkt = (T + bk - 1) / bk;
-    if (split_k > nkt) split_k = nkt;
-    const int k_per_split = ((nkt + split_k - 1) / split_k) * bk;
-    const int splits_eff = (nkt + (k_per_split / bk) - 1) / (k_per_split / bk);
+    int eff[POLUS_MAX_GROUP], kps[POLUS_MAX_GROUP];
+    for (int k = 0; k < n; ++k) {
+        int sk = splits[k] > nkt ? nkt : splits[k];
+        kps[k] = ((nkt + sk - 1) / sk) * bk;
+        eff[k] = (nkt + (kps[k] / bk) - 1) / (kps[k] / bk);
+    }
     size_t so[POLUS_MAX_GROUP], co[POLUS_MAX_GROUP];
-    grouped_need(n, problems, splits_eff > 1 ? split_k : 1, so, co);
+    grouped_need(n, problems, splits, so, co);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     GemmArgs ga[POLUS_MAX_GROUP];
     int ablate = 0;
@@ -586,11 +627,11 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         memset(&a, 0, sizeof(a));
         a.A = q.dY; a.B = q.X; a.lda = q.lddy; a.ldb = q.ldx;
         a.M = q.n_out; a.N = q.n_in; a.K = T; a.alpha = 1.0f;
-        a.k_per_split = k_per_split;
+        a.k_per_split = kps[k];
         a.a_vec = a.b_vec = 1;
         a.colsum_a = q.db ? reinterpret_cast<float*>(ws + co[k]) : nullptr;
         a.ablate = ablate;
-        if (splits_eff > 1) {
+        if (eff[k] > 1) {
             a.C = ws + so[k]; a.ldc = q.n_in; a.c_split_stride = (long)q.n_out * q.n_in;
             a.epi_vec = a.epi_vec16 = (q.n_in % 4 == 0);
         } else {
@@ -598,20 +639,20 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
             a.epi_vec = polus_aligned16(q.dW) && (q.lddw % 4 == 0); a.epi_vec16 = a.epi_vec;
         }
     }
-    int rc = polus_launch_gemm_ring_grouped_dw(ga, n, splits_eff, st);
+    int rc = polus_launch_gemm_ring_grouped_dw(ga, n, eff, st);
     if (rc != POLUS_OK) return rc;
     for (int k = 0; k < n; ++k) {
         const polus_dw_problem& q = problems[k];
-        if (splits_eff > 1) {
+        if (eff[k] > 1) {
             long total = (long)q.n_out * q.n_in;
             hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((int)((total + 255) / 256)), dim3(256), 0, st,
-                               reinterpret_cast<const float*>(ws + so[k]), splits_eff, q.n_out, q.n_in, q.dW, q.lddw, 1.0f,
+                               reinterpret_cast<const float*>(ws + so[k]), eff[k], q.n_out, q.n_in, q.dW, q.lddw, 1.0f,
                                (const float*)nullptr, accumulate ? 1 : 0);
             POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(reduce)");
         }
         if (q.db) {
             hipLaunchKernelGGL(colsum_splits_kernel, dim3((q.n_out + 255) / 256), dim3(256), 0, st,
-                               reinterpret_cast<const float*>(ws + co[k]), splits_eff, q.n_out, q.db, accumulate ? 1 : 0);
+                               reinterpret_cast<const float*>(ws + co[k]), eff[k], q.n_out, q.db, accumulate ? 1 : 0);
             POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(colsum)");
         }
     }

@@ -363,7 +363,7 @@ int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st)
 int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st);
 // several dW problems (both operands K-strided, f32 C / slabs, same K and k_per_split) in one launch
 #define POLUS_MAX_GROUP 8
-int polus_launch_gemm_ring_grouped_dw(const pgemm::GemmArgs* probs, int n, int splits, hipStream_t st);
+int polus_launch_gemm_ring_grouped_dw(const pgemm::GemmArgs* probs, int n, const int* splits, hipStream_t st);
 // dropout epilogue (POLUS_GEMM_DROPOUT): bf16 C, both operands K-contiguous only.
 int polus_launch_gemm_ring_dropout(const pgemm::GemmArgs& a, hipStream_t st);
 // gemm_p.hip: persistent 256 x tn tile (tn = 192), one workgroup per CU, both operands K-contiguous, K % 64 == 0.

@@ -219,14 +219,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
 }
 
 // Several problems with the same contraction length in one launch (the dW = dY^T X of all four
-// Dense layers of an encoder layer): blockIdx.x runs over the concatenated tile lists (each
-// problem's range padded to a multiple of 8 so that workgroup index mod 8 stays the XCD),
-// blockIdx.y over the K-splits.  One problem alone leaves most of the 512 workgroup slots
-// empty unless K is cut into many splits, each of which costs an f32 slab to write and re-read.
+// Dense layers of an encoder layer): blockIdx.x runs over the concatenated (split, tile) lists of
+// the problems (each tile list padded to a multiple of 8 so that workgroup index mod 8 stays the
+// XCD).  One problem alone leaves most of the 512 workgroup slots empty unless K is cut into many
+// splits, each of which costs an f32 slab to write and re-read; together they need 2-3, chosen per
+// problem so that the launch is one full round of slots.
 struct RingGroupArgs {
     GemmArgs p[POLUS_MAX_GROUP];
-    int tile0[POLUS_MAX_GROUP + 1];   // first workgroup of each problem (padded), ascending
+    int wg0[POLUS_MAX_GROUP + 1];     // first workgroup of each problem, ascending
     int tiles[POLUS_MAX_GROUP];       // real tiles of each problem
+    int tpad[POLUS_MAX_GROUP];        // tiles rounded up to a multiple of 8
     int n;
 };
 template <typename TC, bool A_KS, bool B_KS>
@@ -235,8 +237,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ring_grouped_kernel(RingGroupArg
     int q = 0;
 #pragma unroll
     for (int k = 1; k < POLUS_MAX_GROUP; ++k)
-        if (k < ga.n && b >= ga.tile0[k]) q = k;
-    const int wg = b - ga.tile0[q];
+        if (k < ga.n && b >= ga.wg0[k]) q = k;
+    const int rel = b - ga.wg0[q];
+    const int split = rel / ga.tpad[q], wg = rel - split * ga.tpad[q];
     if (wg >= ga.tiles[q]) return;          // padding workgroup
     // ga.p[q] with a run-time q would put the by-value argument array into scratch: read the
     // chosen problem straight out of the kernarg segment (scalar loads) into a local copy instead
@@ -257,7 +260,7 @@ typedef __attribute__((address_space(1))) void gvoid_t;
         P.bias = (const float*)(const gfloat_t*)P.bias; P.resid = (const void*)(const gvoid_t*)P.resid;
         P.aux = (void*)(gvoid_t*)P.aux; P.partial = (float*)(gfloat_t*)P.partial; P.colsum_a = (float*)(gfloat_t*)P.colsum_a;
     }
-    ring_body<TC, A_KS, B_KS, false>(P, wg, ga.tiles[q], blockIdx.y);
+    ring_body<TC, A_KS, B_KS, false>(P, wg, ga.tiles[q], split);
 }
 
 template <typename TC, bool A_KS, bool B_KS, bool DROP = false, int MODE = -1>
@@ -285,7 +288,7 @@ int launch_layout(const GemmArgs& a, int a_ks, int b_ks, int splits, hipStream_t
 
 }  // namespace
 
-int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, int splits, hipStream_t st) {
+int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, const int* splits, hipStream_t st) {
     static bool attr_done = false;
     auto kern = gemm_ring_grouped_kernel<float, true, true>;
     if (!attr_done) {
@@ -300,11 +303,12 @@ int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, int splits, 
     for (int k = 0; k < n; ++k) {
         ga.p[k] = probs[k];
         ga.tiles[k] = ((probs[k].M + TM - 1) / TM) * ((probs[k].N + TN - 1) / TN);
-        ga.tile0[k] = t0;
-        t0 += (ga.tiles[k] + 7) / 8 * 8;
+        ga.tpad[k] = (ga.tiles[k] + 7) / 8 * 8;
+        ga.wg0[k] = t0;
+        t0 += ga.tpad[k] * splits[k];
     }
-    ga.tile0[n] = t0;
-    hipLaunchKernelGGL(kern, dim3(t0, splits), dim3(NTHR), SMEM_BYTES, st, ga);
+    ga.wg0[n] = t0;
+    hipLaunchKernelGGL(kern, dim3(t0), dim3(NTHR), SMEM_BYTES, st, ga);
     POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(ring)");
     return POLUS_OK;
 }

@@ -63,8 +63,7 @@ def dense_bwd_params_group(problems, accumulate=False):
     f32 engine (128x128 exact-f32 kernel) runs them one by one with per-matrix split-K."""
     T = problems[0][0].shape[0]
     if problems[0][0].dtype == torch.bfloat16 and os.environ.get("POLUS_DW_UNGROUPED") is None:
-        shapes = [(dy.shape[1], x.shape[1]) for dy, x, _, _ in problems]
-        return ops.dense_bwd_params_grouped(problems, accumulate, dw_group_split_k(shapes, T))
+        return ops.dense_bwd_params_grouped(problems, accumulate, 0)      # 0: per-problem splits chosen by the library
     for dy, x, dw, db in problems:
         sk = dw_split_k(dy.shape[1], x.shape[1], T)
         if db is not None:
