@@ -186,7 +186,7 @@ def main():
             peak = PEAK_TFLOPS[args.dtype]
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": None,
-                    "kernel": ("gemm_ring_kernel<bf16, K-contig, K-contig> / gemm_p_kernel<192>" if args.dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig>")
+                    "kernel": ("gemm_ring_kernel<bf16, K-contig, K-contig, epilogue mode 0-3>" if args.dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig>")
                               + " (every K-contiguous Dense GEMM of the step: forward QKV, out-proj, FFN1, FFN2 and their"
                                 " input gradients dX = dY.W^T-shadow; the remaining GEMMs are the K-strided dW = dY^T.X)",
                     "launches": len(fwd), "avg_launch_us": round(tsum / len(fwd) * 1e6, 2),
