@@ -57,7 +57,7 @@ __device__ __forceinline__ void dma_piece(const bf16_t* __restrict__ base, long 
 
 #define POLUS_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <typename TC>
+template <typename TC, int MODE = -1>
 __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -207,13 +207,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(GemmArgs p) {
     // every wave is done with the operand stages (and no DMA is in flight): reuse LDS for the C staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    epilogue_wave_128x64_lds<TC, false>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    if (MODE >= 0) epilogue_wave<TC, 64, false, MODE < 0 ? 0 : MODE, false>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
+    else epilogue_wave_128x64_lds<TC, false>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
-template <typename TC>
+template <typename TC, int MODE = -1>
 int launch256(const GemmArgs& a, hipStream_t st) {
     static bool attr_done = false;
-    auto kern = gemm256_kernel<TC>;
+    auto kern = gemm256_kernel<TC, MODE>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
@@ -228,5 +229,14 @@ int launch256(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 int polus_launch_gemm256(const GemmArgs& a, int c_is_f32, hipStream_t st) {
+    if (!c_is_f32) {
+        switch (polus_gemm_p_mode(a, 0, 0)) {
+            case 0: return launch256<bf16_t, 0>(a, st);
+            case 1: return launch256<bf16_t, 1>(a, st);
+            case 2: return launch256<bf16_t, 2>(a, st);
+            case 3: return launch256<bf16_t, 3>(a, st);
+            default: break;
+        }
+    }
     return c_is_f32 ? launch256<float>(a, st) : launch256<bf16_t>(a, st);
 }
