@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .layers import CRF, Dense, Dropout, Flatten, Layer, dense_bwd_params_group, gemm_dx
 from .tensor import ParamArena, to_device, device
 
@@ -174,7 +174,7 @@ class BertLayer:
                 self._ev = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev[0].record(main)
             side.wait_event(self._ev[0])
-            with torch.cuda.stream(side):
+            with _lib.stream_scope(side):
                 dense_bwd_params_group(problems, accumulate)
                 self._ev[1].record(side)
             self.dw_done = self._ev[1]

@@ -38,7 +38,7 @@ _WS = {}
 
 
 def workspace(device):
-    key = (str(device), torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    key = (device if isinstance(device, str) else str(device), _lib.current_stream() if torch.cuda.is_available() else 0)
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = Workspace(device)

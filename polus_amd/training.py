@@ -8,7 +8,7 @@ a bucketed RCCL all-reduce that starts while backward is still running, and
 """
 import os
 
-from . import comm
+from . import _lib, comm
 from .callbacks import CallbackCoordinator, Profiler
 from .context import PolusContext, logger
 
@@ -87,6 +87,10 @@ class BaseTrainer:
     def train_step(self, *inputs):
         """polus/training.py:150-193, same order: forward_without_grads -> forward_with_grads
         -> loss -> gradients (all-reduced across ranks) -> post_process_grads -> apply."""
+        with _lib.pinned_stream():      # one stream lookup per step instead of one per launch
+            return self._train_step(*inputs)
+
+    def _train_step(self, *inputs):
         micro = self.step_counter_micro = getattr(self, "step_counter_micro", 0)
         accum = self.grad_accum_steps
         first, last = (micro % accum == 0), (micro % accum == accum - 1)
