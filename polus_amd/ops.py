@@ -37,8 +37,14 @@ class Workspace:
 _WS = {}
 
 
+_HAS_GPU = None
+
+
 def workspace(device):
-    key = (device if isinstance(device, str) else str(device), _lib.current_stream() if torch.cuda.is_available() else 0)
+    global _HAS_GPU
+    if _HAS_GPU is None:
+        _HAS_GPU = torch.cuda.is_available()      # ~20 us per call otherwise, once per launch
+    key = (device, _lib.current_stream() if _HAS_GPU else 0)
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = Workspace(device)

@@ -75,29 +75,35 @@ class Variable:
         self.size = int(np.prod(self.shape))
         self.offset = None
 
-    def _view(self, flat):
-        return flat[self.offset:self.offset + self.size].view(self.shape)
+    def _view(self, flat, key, shape=None):
+        # views of the flat arenas are made once per (variable, arena tensor): the layers ask for
+        # them ~500 times per step
+        c = self.__dict__.setdefault("_views", {})
+        v = c.get(key)
+        if v is None or v[0] is not flat:
+            v = c[key] = (flat, flat[self.offset:self.offset + self.size].view(shape or self.shape))
+        return v[1]
 
     @property
     def value(self):
-        return self._view(self.arena.params)
+        return self._view(self.arena.params, "p")
 
     @property
     def grad(self):
-        return self._view(self.arena.grads)
+        return self._view(self.arena.grads, "g")
 
     @property
     def compute_t(self):
         """bf16 transposed shadow [in, out] (K-contiguous B operand of dX = dY . W), or None."""
         if self.arena.shadow_t is not None and self.matrix and len(self.shape) == 2:
-            return self.arena.shadow_t[self.offset:self.offset + self.size].view(self.shape[1], self.shape[0])
+            return self._view(self.arena.shadow_t, "t", (self.shape[1], self.shape[0]))
         return None
 
     @property
     def compute(self):
         """The tensor GEMMs read: the bf16 shadow in bf16 mode, the f32 master otherwise."""
         if self.arena.shadow is not None and self.matrix:
-            return self._view(self.arena.shadow)
+            return self._view(self.arena.shadow, "s")
         return self.value
 
     def numpy(self):
