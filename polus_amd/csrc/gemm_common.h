@@ -265,9 +265,13 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
             for (int r = 0; r < 8; ++r) bv[ps][r] = 0.f;
         }
     }
-    // residual / aux rows are fetched one m-tile ahead, so the (in-order) wait for them only has
-    // to get past the previous m-tile's stores' *issue*, never their completion
-    bf16x8_t pre[2][2][PASSES];
+    // residual / aux rows are fetched DEPTH m-tiles ahead, so the (in-order) wait for them only has
+    // to get past the previous m-tiles' stores' *issue*, never their completion.  In the training step
+    // these rows come from HBM (written a layer or a whole forward pass earlier): with VGPR
+    // accumulators (ring kernel, 64 spare registers) the prefetch distance is 4 m-tiles, with AGPR
+    // accumulators (persistent kernel, fragments of the next tile live) 1.
+    constexpr int DEPTH = AGPR ? 1 : 4, NBUF = DEPTH + 1;
+    bf16x8_t pre[NBUF][2][PASSES];
     auto fetch = [&](int mt, bf16x8_t (&dst)[2][PASSES]) {
         const T* base = has_resid ? resid : static_cast<const T*>(aux);
         const long ld = has_resid ? p.ldr : p.ldaux;
@@ -277,13 +281,16 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
             for (int ps = 0; ps < PASSES; ++ps)
                 dst[h][ps] = *reinterpret_cast<const bf16x8_t*>(base + (long)(mb + mt * 16 + h * 8 + prow[ps]) * ld + nb + pcol[ps]);
     };
-    if (has_resid || act_bwd) fetch(0, pre[0]);
+    if (has_resid || act_bwd) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, pre[d % NBUF]);
+    }
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < 8; ++mt) {
         f32x4 t[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) t[nt] = acc_take<AGPR>(acc[mt][nt]);
-        if ((has_resid || act_bwd) && mt < 7) fetch(mt + 1, pre[(mt + 1) & 1]);
+        if ((has_resid || act_bwd) && mt + DEPTH < 8) fetch(mt + DEPTH, pre[(mt + DEPTH) % NBUF]);
 #pragma clang loop unroll(full)
         for (int h = 0; h < 2; ++h) {
             // rows 8h..8h+7 of the m-tile live in lanes with (i>>3) == h; the other lanes write to a
@@ -318,7 +325,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
                 if (act_bwd) {
                     float u[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) u[r] = (float)pre[mt & 1][h][ps][r];
+                    for (int r = 0; r < 8; ++r) u[r] = (float)pre[mt % NBUF][h][ps][r];
                     apply_act_grad_n<8, true>(p.act, v, u);
                 }
                 if (DROP) {
@@ -327,7 +334,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
                 }
                 if (has_resid) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += (float)pre[mt & 1][h][ps][r];
+                    for (int r = 0; r < 8; ++r) v[r] += (float)pre[mt % NBUF][h][ps][r];
                 }
                 if (live) {
                     if (sizeof(TC) == 4) {
