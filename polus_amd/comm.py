@@ -173,10 +173,21 @@ class GradBucketReducer:
             self.launched_bytes += view.numel() * view.element_size()
             self._next += 1
 
-    def finish(self):
-        """Flush what is left and make the current stream wait for every bucket."""
+    def finish(self, keep_last=False):
+        """Flush what is left and make the current stream wait for every bucket.
+        keep_last: leave the last bucket (the front of the arena: the embeddings, whose gradient
+        is the last thing backward produces) in flight and return its upper offset -- the caller
+        updates the parameters above it first and then calls finish_last().  Returns None when
+        there is nothing to keep (a single bucket)."""
         self._ready_lo = 0
         self._launch_ready()
+        keep = keep_last and len(self._works) > 1 and self._next == len(self.buckets)
+        for w in (self._works[:-1] if keep else self._works):
+            w.wait()
+        self._works = self._works[-1:] if keep else []
+        return self.buckets[-1][1] if keep else None
+
+    def finish_last(self):
         for w in self._works:
             w.wait()
         self._works = []

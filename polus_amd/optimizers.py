@@ -117,12 +117,17 @@ class Adam:
             self._tables[key] = t
         return t
 
-    def apply_gradients(self, grads_and_vars):
+    def apply_gradients(self, grads_and_vars, _advance=True, _refresh=True):
         """`grads` are the arena gradient windows of the variables (the trainer passes
-        ``v.grad``); one fused launch per arena."""
+        ``v.grad``); one fused launch per arena.  `_advance=False` applies the SAME step (count,
+        learning rate) to further variables -- the data-parallel trainer updates the encoder while
+        the embedding gradients are still being all-reduced; `_refresh=False` postpones the
+        transposed-shadow refresh to that second call."""
         variables = [v for _, v in grads_and_vars]
-        lr = self.learning_rate(self.iterations)
-        self.iterations += 1
+        if _advance:
+            self._lr_now = self.learning_rate(self.iterations)
+            self.iterations += 1
+        lr = self._lr_now
         t = self.iterations
         lr_t = lr * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         arenas = {}
@@ -140,7 +145,8 @@ class Adam:
             ops.adam_step(arena.params, arena.grads, m, v, arena.shadow, seg, n_seg, lr, lr_t,
                           self.beta_1, self.beta_2, self.epsilon, self.weight_decay_rate,
                           grad_scale=self.grad_scale, clip_scale=clip)
-            arena.refresh_transposed()
+            if _refresh:
+                arena.refresh_transposed()
 
 
 class AdamWeightDecay(Adam):

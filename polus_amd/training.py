@@ -9,6 +9,7 @@ a bucketed RCCL all-reduce that starts while backward is still running, and
 import os
 
 from . import _lib, comm
+from .optimizers import Adam
 from .callbacks import CallbackCoordinator, Profiler
 from .context import PolusContext, logger
 
@@ -117,10 +118,20 @@ class BaseTrainer:
                 reducers = [self._reducer(a) for a in self._arenas()]
                 for r in reducers:
                     r.begin()
-            for r in reducers:
-                r.finish()
+            # One arena, a fused optimizer and nothing that needs all gradients at once: keep the last
+            # bucket (the embeddings) in flight and update everything above it meanwhile.
+            can_split = (len(reducers) == 1 and self.post_process_grads is None and accum == 1 and
+                         isinstance(self.optimizer, Adam) and not self.optimizer.global_clipnorm and
+                         os.environ.get("POLUS_DP_SPLIT_ADAM", "1") != "0" and
+                         all(v.arena.grads is reducers[0].grads for v in self.trainable_weights))
+            split_at = reducers[0].finish(keep_last=True) if can_split else None
+            if not can_split:
+                for r in reducers:
+                    r.finish()
             if hasattr(self.model, "grad_ready_hook"):
                 self.model.grad_ready_hook = None
+        else:
+            split_at = None
 
         # gradients hold the SUM over ranks and micro-steps; the mean is taken inside the
         # fused optimizer kernel
@@ -135,7 +146,15 @@ class BaseTrainer:
             grads = self.post_process_grads(grads)
         if hasattr(self.optimizer, "grad_scale"):
             self.optimizer.grad_scale = scale
-        self.optimizer.apply_gradients(zip(grads, self.trainable_weights))
+        if split_at is not None:
+            upper = [v for v in self.trainable_weights if v.offset >= split_at]
+            lower = [v for v in self.trainable_weights if v.offset < split_at]
+            self.optimizer.apply_gradients([(v.grad, v) for v in upper], _refresh=not lower)
+            reducers[0].finish_last()
+            if lower:
+                self.optimizer.apply_gradients([(v.grad, v) for v in lower], _advance=False)
+        else:
+            self.optimizer.apply_gradients(zip(grads, self.trainable_weights))
         return loss_value
 
     def lr_finder(self, tf_dataset, use_lr_found=False):

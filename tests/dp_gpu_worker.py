@@ -41,7 +41,14 @@ def main():
         ids, mask, tt, labels = synth_batch(ocfg, 4, 16, 4, 420 + s)
         batches.append(({"input_ids": ids[mine], "attention_mask": mask[mine], "token_type_ids": tt[mine]},
                         labels[mine]))
+    calls = []
+    orig = opt.apply_gradients
+    opt.apply_gradients = lambda gv, **kw: (calls.append((len(list(gv)) if not isinstance(gv, list) else len(gv), kw)), orig(gv, **kw))[1]
     trainer.train(batches, epochs=1, callbacks=[])
+    # the update is split around the last all-reduce bucket: two launches per step, every variable once
+    assert len(calls) == 2 * steps and all(calls[2 * k][0] + calls[2 * k + 1][0] == len(trainer.trainable_weights)
+                                           for k in range(steps)), calls
+    assert all(calls[2 * k + 1][1].get("_advance") is False for k in range(steps))
     # the parent compares parameters, which depend on every step's averaged gradients
     flat = model.arena.params.detach().float().cpu().numpy()
     np.save(f"{out}.rank{rank}.npy", flat)
