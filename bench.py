@@ -94,7 +94,6 @@ def main():
     ap.add_argument("--large", action="store_true", help="BERT-large instead of BERT-base")
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden and attention dropout (HF BERT default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     args = ap.parse_args()
 
     import torch
