@@ -1,5 +1,7 @@
-// bf16 MFMA GEMM, persistent, 256 x TN tile (TN = 192 or 256), ONE 4-wave workgroup per CU (gfx950).
-// C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous.
+// bf16 MFMA GEMM, persistent, 256 x 192 tile, ONE 4-wave workgroup per CU (gfx950).
+// C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous.  OPT-IN (POLUS_GEMM_P=1|2): since the ring
+// kernel got compile-time epilogue modes the two tie in the training step; kept because it is the
+// base for the larger-tile work and is covered by the GPU tests.
 //
 // Why this shape: the operand fill path (L2 -> LDS) tops out near 10 TB/s for the whole chip
 // (profiles/README.md), so FLOP per filled byte is what sets the ceiling: 256x128 = 85 FLOP/B
@@ -10,13 +12,15 @@
 //   * persistent: grid = #CUs; workgroup w walks tiles w, w+grid, ... and the LDS-DMA ring runs
 //     over the FLATTENED (tile, k-step) sequence, so the next tile's first stages are in flight
 //     while this tile's epilogue runs (no prologue bubble per tile);
-//   * ring of 4 stages (K-step 32, A 256 rows x 64 B | B TN rows x 64 B): step s reads next
+//   * ring of NS = 5 stages (K-step 32, A 256 rows x 64 B | B TN rows x 64 B): step s reads next
 //     step's fragments from stage s+1 while its MFMAs run on registers loaded in step s-1;
-//     stages s+2, s+3, s+4 are in flight.  One `s_waitcnt vmcnt(2*ND)` + one raw s_barrier per
-//     K-step (ND = DMA instructions per wave per stage);
-//   * vmcnt retires in order, so the epilogue's own loads/stores only make the counted waits
-//     conservative (they are younger than the stages the waits are about).
-// TN = 192 divides every Dense width of BERT-base/large evenly AND makes tiles a multiple of 256
+//     stages s+2 .. s+NS are in flight.  One `s_waitcnt vmcnt((NS-2)*ND)` + one raw s_barrier
+//     per K-step (ND = DMA instructions per wave per stage).  (4 vs 5 stages measure the same:
+//     the fill path is bandwidth-, not latency-bound.)
+//   * LOADS retire in order among themselves, but stores may retire before older loads: a counted
+//     wait may only count younger loads, so the first steps after an epilogue also wait for its C
+//     stores (a wait that discounted the stores raced: a stage was read before it had landed).
+// TN = 192 divides every Dense width of BERT-base evenly AND makes tiles a multiple of 256
 // at T = 16384 (N = 768: 256 tiles, 2304: 768, 3072: 1024) -- no tail round.
 // Same swizzle as gemm_ring.hip: LDS chunk pc of row r holds K-chunk pc ^ pi((r>>2)&3).
 #include <type_traits>
