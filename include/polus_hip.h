@@ -50,6 +50,9 @@ const char* polus_last_error(void);
 int polus_abi_version(void);
 /* host out-params; arch is a NUL-terminated gcnArchName prefix (e.g. "gfx950") */
 int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len);
+/* The POLUS_* tuning switches of the library are read from the environment once, at the first call
+ * that needs one; this re-reads them (A/B tools and tests that flip a switch inside one process). */
+int polus_reload_env(void);
 
 /* ---- GEMM (HF Dense layers + their gradients; tape.gradient at polus/training.py:185)
  * C[M,N] = epilogue(alpha * A_op[M,K] . B_op[K,N]).

@@ -22,6 +22,7 @@ SIGNATURES = {
     "polus_last_error": (_c.c_char_p, []),
     "polus_abi_version": (_i, []),
     "polus_device_info": (_i, [_c.POINTER(_i), _c.POINTER(_i), _c.c_char_p, _i]),
+    "polus_reload_env": (_i, []),
     "polus_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_gemm": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,
                         _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),

@@ -455,8 +455,8 @@ int launch_wide_nw(const AttnArgs& a, hipStream_t st) {
 template <int WHICH>
 int launch_wide(int dtype, const AttnArgs& a, hipStream_t st) {
     if (dtype != POLUS_BF16) return launch_wide_nw<WHICH, float, 4>(a, st);
-    const char* e = getenv("POLUS_ATTN_WAVES");
-    int nw = e ? atoi(e) : (a.S >= 96 ? 8 : 4);
+    const int forced = polus_cfg().attn_waves;
+    int nw = forced > 0 ? forced : (a.S >= 96 ? 8 : 4);
     if (nw >= 16) return launch_wide_nw<WHICH, bf16_t, 16>(a, st);
     if (nw >= 8) return launch_wide_nw<WHICH, bf16_t, 8>(a, st);
     return launch_wide_nw<WHICH, bf16_t, 4>(a, st);

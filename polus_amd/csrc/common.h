@@ -27,6 +27,22 @@ void polus_set_error(const char* fmt, ...);
 static inline size_t polus_dtype_size(int dt) { return dt == POLUS_BF16 ? 2 : 4; }
 static inline bool polus_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ---------------------------------------------------------------- tuning knobs (host)
+// The POLUS_* environment switches (A/B runs, tests) are read ONCE at library load -- a getenv per
+// launch sat on the launch path of every GEMM -- and again only through polus_reload_env().
+struct PolusCfg {
+    int gemm_p;            // POLUS_GEMM_P: 0 off, 1 persistent 256x192 where a tile writes little per FLOP, 2 wherever legal
+    int gemm_pp;           // POLUS_GEMM_PP: -1 off, 0 per-shape choice (default), 256 / 192 force that tile where legal
+    int gemm_v1;           // POLUS_GEMM_V1: 128x128 register-staged kernel for everything
+    int gemm_256;          // POLUS_GEMM_256: one-workgroup-per-CU 256x256 kernel (A/B)
+    int ring_runtime_epi;  // POLUS_RING_RUNTIME_EPI: ring kernel with run-time epilogue flags (A/B)
+    int dw_ungrouped;      // POLUS_DW_UNGROUPED: one dW launch per matrix
+    int ablate;            // POLUS_GEMM_ABLATE: diagnostics (bit0 no in-loop DMA, bit1 no MFMA)
+    int attn_waves;        // POLUS_ATTN_WAVES: 0 default
+    int dw_fused_reduce;   // POLUS_DW_FUSED_REDUCE: 1 (default) one reduce launch per grouped dW
+};
+const PolusCfg& polus_cfg();
+
 // ---------------------------------------------------------------- scalar conversions
 template <typename T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }

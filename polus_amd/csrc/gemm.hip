@@ -277,8 +277,7 @@ static int polus_num_cus() {
 // write per FLOP (N <= K, no second store or load stream), POLUS_GEMM_P=2 wherever it is legal
 // (tests).  Needs K % 64 == 0, N % 192 == 0 and (nearly) full rounds of #CU tiles.
 static bool use_persistent(int M, int N, int K, int mode) {
-    const char* e = getenv("POLUS_GEMM_P");
-    const int sel = e ? atoi(e) : 0;
+    const int sel = polus_cfg().gemm_p;
     if (sel == 0 || mode < 0 || K % 64 != 0 || M < 256 || N < 192) return false;
     if (sel == 2) return true;
     if (!(mode == 0 || mode == 2) || N > K || (N % 192) != 0) return false;
@@ -286,6 +285,28 @@ static bool use_persistent(int M, int N, int K, int mode) {
     const long tiles = (long)((M + 255) / 256) * (N / 192);
     const long rounds = (tiles + ncu - 1) / ncu;
     return tiles * 100 >= rounds * ncu * 90;
+}
+
+// The ping-pong kernel (gemm_pp.hip, one 8-wave workgroup per CU, 256 x 256 or 256 x 192 tile): more
+// FLOP per byte filled into LDS than the ring kernel's 256 x 128, which is what bounds these GEMMs.
+// Returns the tile width to use, 0 = stay on the ring kernel.  Needs K % 64 == 0, a compile-time
+// epilogue mode and enough tiles to fill the chip: a launch is whole rounds of #CU tiles, so the
+// tile width is chosen by the share of the last round that is busy (256 is ~10 % faster per tile).
+static int pp_tile(int M, int N, int K, int mode, bool vec16) {
+    const int sel = polus_cfg().gemm_pp;
+    if (sel < 0 || mode < 0 || K % 64 != 0 || M < 256 || N < 192 || !vec16) return 0;
+    if (sel == 256 || sel == 192) return sel;
+    const int ncu = polus_num_cus();
+    const long tm = (M + 255) / 256;
+    double best = 0.0; int best_tn = 0;
+    for (int tn : {256, 192}) {
+        const long tiles = tm * ((N + tn - 1) / tn);
+        const long rounds = (tiles + ncu - 1) / ncu;
+        const double useful = (double)M * N / ((double)rounds * ncu * 256.0 * tn);   // busy share incl. edge waste
+        const double score = useful * (tn == 256 ? 1.10 : 1.0);
+        if (score > best) { best = score; best_tn = tn; }
+    }
+    return best >= 0.70 ? best_tn : 0;
 }
 
 static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
@@ -373,7 +394,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     if (resid) ev16 = ev16 && (((uintptr_t)resid) % 16 == 0) && ((ldr * es) % 16 == 0);
     if (aux) ev16 = ev16 && (((uintptr_t)aux) % 16 == 0) && ((ldaux * es) % 16 == 0);
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
-    { const char* ab = getenv("POLUS_GEMM_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    a.ablate = polus_cfg().ablate;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
@@ -385,8 +406,10 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     if (flags & POLUS_GEMM_DROPOUT) {
         // forward Dense only: K-contiguous operands, C in the compute dtype
         POLUS_REQUIRE(both_kc && c_dtype == dtype, "polus_gemm_dropout: needs K-contiguous operands and c_dtype == dtype");
-        if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
+        if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !polus_cfg().gemm_v1) {
             a.k_per_split = ((K + 31) / 32) * 32;
+            if (const int tn = pp_tile(M, N, K, polus_gemm_p_mode(a, 0, 1), a.epi_vec16))
+                return polus_launch_gemm_pp(a, polus_gemm_p_mode(a, 0, 1), 1, tn, st);
             if (use_persistent(M, N, K, polus_gemm_p_mode(a, 0, 1))) return polus_launch_gemm_p(a, polus_gemm_p_mode(a, 0, 1), 1, 192, polus_num_cus(), st);
             return polus_launch_gemm_ring_dropout(a, st);
         }
@@ -395,11 +418,15 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
         return v ? launch_v<float, false, false, float, true, true>(a, grid, st) : launch_v<float, false, false, float, false, true>(a, grid, st);
     }
     const int a_ks = a_layout == POLUS_K_STRIDED, b_ks = b_layout == POLUS_K_STRIDED;
-    if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !getenv("POLUS_GEMM_V1")) {
+    if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !polus_cfg().gemm_v1) {
         if (split_k <= 1) {
             // POLUS_GEMM_256=1 selects the one-workgroup-per-CU 256x256 kernel (kept for A/B runs)
-            if (both_kc && getenv("POLUS_GEMM_256") && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
+            if (both_kc && polus_cfg().gemm_256 && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
             a.k_per_split = ((K + 31) / 32) * 32;
+            if (both_kc) {
+                if (const int tn = pp_tile(M, N, K, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), a.epi_vec16))
+                    return polus_launch_gemm_pp(a, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), 0, tn, st);
+            }
             if (both_kc && use_persistent(M, N, K, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0)))
                 return polus_launch_gemm_p(a, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), 0, 192, polus_num_cus(), st);
             return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, a_ks, b_ks, 1, st);
@@ -475,7 +502,7 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     float* cs_ws = reinterpret_cast<float*>(ws + slab_bytes);
     const bool vec = polus_aligned16(dY) && polus_aligned16(X) && ((lddy * es) % 16 == 0) && ((ldx * es) % 16 == 0) &&
                      (n_out % (16 / es) == 0) && (n_in % (16 / es) == 0);
-    const bool ring = dtype == POLUS_BF16 && vec && n_out >= 256 && n_in >= 128 && db != nullptr && !getenv("POLUS_GEMM_V1");
+    const bool ring = dtype == POLUS_BF16 && vec && n_out >= 256 && n_in >= 128 && db != nullptr && !polus_cfg().gemm_v1;
     if (!ring) {
         int rc = polus_gemm(dtype, POLUS_K_STRIDED, POLUS_K_STRIDED, POLUS_F32, dY, lddy, X, ldx, dW, lddw, n_out, n_in, T,
                             1.0f, nullptr, nullptr, 0, nullptr, 0, 0, accumulate ? POLUS_GEMM_ACCUM_C : 0, split_k,
@@ -491,7 +518,7 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     const int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     a.a_vec = a.b_vec = 1;
     a.colsum_a = cs_ws;
-    { const char* ab = getenv("POLUS_GEMM_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+    a.ablate = polus_cfg().ablate;
     int rc;
     if (splits_eff > 1) {
         a.C = ws; a.ldc = n_in; a.c_split_stride = (long)n_out * n_in;
@@ -582,7 +609,7 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
                                               int split_k, void* workspace, size_t workspace_bytes, void* stream) {
     POLUS_REQUIRE(problems && n >= 1 && n <= POLUS_MAX_GROUP && T > 0, "polus_dense_bwd_params_grouped: bad arguments");
     const size_t es = polus_dtype_size(dtype);
-    bool ring = dtype == POLUS_BF16 && !getenv("POLUS_GEMM_V1") && !getenv("POLUS_DW_UNGROUPED");
+    bool ring = dtype == POLUS_BF16 && !polus_cfg().gemm_v1 && !polus_cfg().dw_ungrouped;
     for (int k = 0; k < n; ++k) {
         const polus_dw_problem& q = problems[k];
         POLUS_REQUIRE(q.dY && q.X && q.dW && q.n_out > 0 && q.n_in > 0, "polus_dense_bwd_params_grouped: problem %d: bad arguments", k);
@@ -620,7 +647,7 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     GemmArgs ga[POLUS_MAX_GROUP];
     int ablate = 0;
-    { const char* ab = getenv("POLUS_GEMM_ABLATE"); ablate = ab ? atoi(ab) : 0; }
+    ablate = polus_cfg().ablate;
     for (int k = 0; k < n; ++k) {
         const polus_dw_problem& q = problems[k];
         GemmArgs& a = ga[k];

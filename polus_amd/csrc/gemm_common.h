@@ -65,11 +65,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const f32x4& ac
     }
     if (p.flags & POLUS_GEMM_ACT_FWD) {
         if (p.aux) st4x<T>(static_cast<T*>(p.aux) + (long)m * p.ldaux + n, v, ev, nvalid);
-        apply_act_n<4>(p.act, v);
+        apply_act_n<4, sizeof(T) == 2>(p.act, v);     // bf16 engine: polynomial GELU on every path (edge tiles too)
     }
     if (p.flags & POLUS_GEMM_ACT_BWD) {
         float u[4]; ld4x<T>(static_cast<const T*>(p.aux) + (long)m * p.ldaux + n, u, ev, nvalid);
-        apply_act_grad_n<4>(p.act, v, u);
+        apply_act_grad_n<4, sizeof(T) == 2>(p.act, v, u);
     }
     if (DROP) {
         const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)n;
@@ -253,8 +253,10 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
     float bv[PASSES][8];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-        int slot = ps * 64 + lane;
-        if (slot >= SLOTS) slot = 0;
+        // lanes past the last slot repeat an earlier slot (same value to the same address) instead of
+        // being masked off: the epilogue stays free of divergent control flow (hipcc 7.2 moved the
+        // staging writes of the following m-tile into such a branch: wrong values from those lanes)
+        const int slot = (ps * 64 + lane) % SLOTS;
         prow[ps] = slot / CPR;
         pcol[ps] = 8 * (slot % CPR);
         if (p.bias) {
@@ -304,7 +306,6 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
             }
 #pragma clang loop unroll(full)
             for (int ps = 0; ps < PASSES; ++ps) {
-                const bool live = !(ps * 64 + 64 > SLOTS) || (ps * 64 + lane < SLOTS);
                 const long m = mb + mt * 16 + h * 8 + prow[ps];
                 const int ncol = nb + pcol[ps];
                 const unsigned char* src = lds + prow[ps] * RS + pcol[ps] * 4;
@@ -313,7 +314,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bv[ps][r];
                 if (act_fwd) {
-                    if (aux && live) {
+                    if (aux) {
                         bf16x8_t tt;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
@@ -336,17 +337,15 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)pre[mt % NBUF][h][ps][r];
                 }
-                if (live) {
-                    if (sizeof(TC) == 4) {
-                        float* dst = reinterpret_cast<float*>(C) + m * p.ldc + ncol;
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    } else {
-                        bf16x8_t tt;
+                if (sizeof(TC) == 4) {
+                    float* dst = reinterpret_cast<float*>(C) + m * p.ldc + ncol;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    bf16x8_t tt;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
-                        *reinterpret_cast<bf16x8_t*>(reinterpret_cast<T*>(C) + m * p.ldc + ncol) = tt;
-                    }
+                    for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x8_t*>(reinterpret_cast<T*>(C) + m * p.ldc + ncol) = tt;
                 }
             }
         }
@@ -376,3 +375,6 @@ int polus_launch_gemm_ring_dropout(const pgemm::GemmArgs& a, hipStream_t st);
 // gemm_p.hip: persistent 256 x tn tile (tn = 192), one workgroup per CU, both operands K-contiguous, K % 64 == 0.
 int polus_gemm_p_mode(const pgemm::GemmArgs& a, int c_is_f32, int drop);   // -1: not built for this epilogue
 int polus_launch_gemm_p(const pgemm::GemmArgs& a, int mode, int drop, int tn, int ncu, hipStream_t st);
+// gemm_pp.hip: 256 x tn tile (tn = 256 or 192), 8 waves in two half-phase-staggered groups, one workgroup per
+// CU, both operands K-contiguous, K % 64 == 0, bf16 C, mode from polus_gemm_p_mode.
+int polus_launch_gemm_pp(const pgemm::GemmArgs& a, int mode, int drop, int tn, hipStream_t st);

@@ -1,0 +1,231 @@
+// bf16 MFMA GEMM, 256 x (256 | 192) tile, 8 waves in two half-phase-staggered groups (gfx950).
+// C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous (forward Dense; dX through the transposed
+// weight shadow), K % 64 == 0, bf16 C with a compile-time epilogue mode (pgemm::epilogue_wave).
+//
+// Why: the operand fill path (L2 -> LDS) delivers ~10 TB/s with the matrix pipe running, so FLOP per
+// filled byte sets the ceiling (profiles/README.md): 256x128 (gemm_ring.hip) 85 -> ~0.9 PF,
+// 256x192 110, 256x256 128 FLOP/B.  A tile that large needs all 8 waves of a CU in ONE workgroup, so
+// nothing else is resident to cover its LDS reads and barriers; here the two wave groups cover each
+// other instead.
+//
+// Waves 2(M) x 4(N): wave (wm, wn) owns rows wm*128.. (8 m-tiles of 16) x columns wn*WN.. (NT = 4 or 3
+// n-tiles), 128 or 96 accumulator registers.  Group g = wm: waves 0-3 / 4-7, one of each on every
+// SIMD.  A K-tile is 64 deep and is consumed in 4 phases of 2 m-tiles x NT n-tiles x 2 k-halves
+// (16 / 12 MFMA 16x16x32).  A phase is   R: issue this phase's LDS-DMA, read its fragments
+//                                         s_barrier (a)
+//                                         M: s_waitcnt lgkmcnt(0), the MFMAs
+//                                         s_barrier (b)
+// and group 1 runs one barrier behind group 0, so between any two barriers one group's M section
+// shares the SIMDs with the other group's R section: the matrix pipe always has a wave to take
+// MFMAs from.  (B fragments are read once per K-tile in phase 0 and kept: 32 / 24 registers.)
+//
+// LDS: 2 stages x (A 256 rows x 128 B | B TN rows x 128 B) = 128 / 112 KiB, filled by
+// global_load_lds_dwordx4 in 8 KiB pieces (one wave-instruction = 8 rows x 128 B, lane-linear, so the
+// bank swizzle sits on the SOURCE address: LDS chunk c of row r holds K-chunk c ^ ((r >> 1) & 7);
+// fragment reads apply the same XOR and every ds_read_b128 lane group hits 16 distinct 16-byte slots).
+// A piece = the 32-row slab q of both wave groups (rows wm*128 + 32q ..), read only in phase q;
+// B pieces = 64 rows each, read only in phase 0.  A region is refilled TWO phases after the phase that
+// read it (the other group reads half a phase later, and reads retire at the lgkmcnt(0) after
+// barrier (a)), with the data of the K-tile two ahead:
+//     phase 0 of tile t: A slab 2 and the last B piece of tile t+1      (2 loads per wave)
+//     phase 1          : A slab 3 of tile t+1                           (1)
+//     phase 2          : A slab 0 and B pieces 0..NB-3 of tile t+2      (NB-1)
+//     phase 3          : A slab 1 and B piece NB-2 of tile t+2          (2)
+// i.e. every byte is in flight for >= 4 phases (~2k cycles of MFMA time).  The only waits are counted:
+// before barrier (a) of phase 3 `vmcnt(NB+2)` (everything issued up to phase 0 has landed: all of tile
+// t+1's B and slabs 0-2), before barrier (a) of phase 2 `vmcnt(2NB+3)` (slab 3 of tile t).  Data is read
+// one phase after the wait + barrier that retired it.
+#include <type_traits>
+#include "gemm_common.h"
+
+using namespace pgemm;
+
+namespace {
+
+constexpr int TM = 256, TK = 64, NTHR = 512;
+constexpr int A_REGION = TM * 128;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+template <int N> __device__ __forceinline__ void vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int NT> struct PPCfg {
+    static constexpr int WN = 16 * NT, TN = 4 * WN, NB = TN / 64;
+    static constexpr int STAGE = A_REGION + TN * 128;
+    static constexpr int SMEM = 2 * STAGE;
+};
+
+template <int NT, bool DROP, int MODE>
+__global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
+    typedef PPCfg<NT> C;
+    constexpr int WN = C::WN, TN = C::TN, NB = C::NB, STAGE = C::STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wid >> 2, wn = wid & 3;
+
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
+    const int nk = p.K / TK;
+
+    // ---- LDS-DMA sources.  Rows past the edge are clamped (their accumulators are never stored).
+    const int lrow = lane >> 3;
+    const bf16_t* a_src;   // slab 0, tile 0; slab q adds 32 q rows, tile t adds 64 t elements
+    const bf16_t* b_src;   // piece 0; piece b adds 64 b rows
+    {
+        const int ar = wm * 128 + 8 * wn + lrow;
+        const int alc = (lane & 7) ^ ((ar >> 1) & 7);
+        a_src = static_cast<const bf16_t*>(p.A) + alc * 8;
+        const int br = 8 * wid + lrow;
+        const int blc = (lane & 7) ^ ((br >> 1) & 7);
+        b_src = static_cast<const bf16_t*>(p.B) + blc * 8;
+    }
+    long a_rowofs[4], b_rowofs[NB];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_rowofs[q] = (long)min(m0 + wm * 128 + 32 * q + 8 * wn + lrow, p.M - 1) * p.lda;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) b_rowofs[b] = (long)min(n0 + 64 * b + 8 * wid + lrow, p.N - 1) * p.ldb;
+    const int a_dst = (wm * 128 + 8 * wn) * 128;          // + 32 q * 128
+    const int b_dst = A_REGION + (8 * wid) * 128;         // + 64 b * 128
+    auto load_a = [&](int tile, int q) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src + a_rowofs[q] + (long)tile * TK),
+                                         (lds_void_t*)(smem + (tile & 1) * STAGE + a_dst + q * 4096), 16, 0, 0);
+    };
+    auto load_b = [&](int tile, int b) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_src + b_rowofs[b] + (long)tile * TK),
+                                         (lds_void_t*)(smem + (tile & 1) * STAGE + b_dst + b * 8192), 16, 0, 0);
+    };
+
+    // ---- fragment addresses: row R = base16 + i, K-chunk 4h + g at physical chunk ^ ((R >> 1) & 7)
+    const int swz = (i >> 1) & 7;
+    const int c0 = (g ^ swz) * 16, c1 = ((4 + g) ^ swz) * 16;
+    const int a_off = (wm * 128 + i) * 128;                // + mt * 2048
+    const int b_off = A_REGION + (wn * WN + i) * 128;      // + nt * 2048
+
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag<bf16_t> bfr[NT][2], af[2][2];
+
+    // ---- prologue: all of tile 0, then what phases 2 and 3 of "tile -1" would have issued
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_a(0, q);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_b(0, b);
+    if (nk > 1) {
+        load_a(1, 0);
+#pragma unroll
+        for (int b = 0; b + 2 < NB; ++b) load_b(1, b);
+        load_a(1, 1);
+        load_b(1, NB - 2);
+        vmcnt<NB + 1>();
+    } else {
+        vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
+
+    // TAIL: 0 = tiles t+1 and t+2 exist, 1 = only t+1, 2 = last tile
+    auto phase = [&](auto P_, auto TAIL_, int t) {
+        constexpr int P = decltype(P_)::value, TAIL = decltype(TAIL_)::value;
+        const unsigned char* st = smem + (t & 1) * STAGE;
+        // R: loads two phases behind the reads that freed their destination
+        if (P == 0 && TAIL <= 1) { load_a(t + 1, 2); load_b(t + 1, NB - 1); }
+        if (P == 1 && TAIL <= 1) { load_a(t + 1, 3); }
+        if (P == 2 && TAIL == 0) {
+            load_a(t + 2, 0);
+#pragma unroll
+            for (int b = 0; b + 2 < NB; ++b) load_b(t + 2, b);
+        }
+        if (P == 3 && TAIL == 0) { load_a(t + 2, 1); load_b(t + 2, NB - 2); }
+        if (P == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 2048 + c0);
+                bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 2048 + c1);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            af[m][0].v = *reinterpret_cast<const bf16x8*>(st + a_off + (2 * P + m) * 2048 + c0);
+            af[m][1].v = *reinterpret_cast<const bf16x8*>(st + a_off + (2 * P + m) * 2048 + c1);
+        }
+        if (P == 2) {
+            if (TAIL == 0) vmcnt<2 * NB + 3>(); else if (TAIL == 1) vmcnt<NB + 4>(); else vmcnt<0>();
+        }
+        if (P == 3) {
+            if (TAIL == 0) vmcnt<NB + 2>(); else if (TAIL == 1) vmcnt<1>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                mma16(acc[2 * P + m][nt], bfr[nt][0], af[m][0]);
+                mma16(acc[2 * P + m][nt], bfr[nt][1], af[m][1]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    auto ktile = [&](auto TAIL_, int t) {
+        phase(std::integral_constant<int, 0>{}, TAIL_, t);
+        phase(std::integral_constant<int, 1>{}, TAIL_, t);
+        phase(std::integral_constant<int, 2>{}, TAIL_, t);
+        phase(std::integral_constant<int, 3>{}, TAIL_, t);
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) { ktile(std::integral_constant<int, 1>{}, t); ++t; }
+    ktile(std::integral_constant<int, 2>{}, t);
+
+    if (wm == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's last barrier (b)
+    // every wave is done with the operand stages and no DMA is in flight: LDS now stages C
+    epilogue_wave<bf16_t, WN, DROP, MODE, false>(p, acc, m0 + wm * 128, n0 + wn * WN, lane,
+                                                 smem + wid * ((EpiCfg<WN>::BYTES + 255) / 256 * 256));
+}
+
+template <int NT, bool DROP, int MODE>
+int launch_pp(const GemmArgs& a, hipStream_t st) {
+    typedef PPCfg<NT> C;
+    static bool attr_done = false;
+    auto kern = gemm_pp_kernel<NT, DROP, MODE>;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
+        attr_done = true;
+    }
+    const int tiles = ((a.M + TM - 1) / TM) * ((a.N + C::TN - 1) / C::TN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), C::SMEM, st, a);
+    POLUS_CHECK_LAUNCH("polus_gemm(ping-pong 256-wide)");
+    return POLUS_OK;
+}
+
+template <int NT>
+int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
+    switch (mode) {
+        case 0: return launch_pp<NT, false, 0>(a, st);
+        case 1: return launch_pp<NT, false, 1>(a, st);
+        case 2: return drop ? launch_pp<NT, true, 2>(a, st) : launch_pp<NT, false, 2>(a, st);
+        case 3: return launch_pp<NT, false, 3>(a, st);
+    }
+    return POLUS_ERR_INVALID;
+}
+
+}  // namespace
+
+// tn = 256 or 192; mode from polus_gemm_p_mode (>= 0); K % 64 == 0; bf16 C; 16-byte aligned rows.
+int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStream_t st) {
+    if (mode < 0 || a.K % TK != 0 || a.K < TK) return POLUS_ERR_INVALID;
+    if (tn == 256) return launch_pp_mode<4>(a, mode, drop, st);
+    if (tn == 192) return launch_pp_mode<3>(a, mode, drop, st);
+    return POLUS_ERR_INVALID;
+}

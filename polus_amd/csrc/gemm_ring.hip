@@ -314,12 +314,12 @@ int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, const int* s
 }
 
 int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
-    if (polus_gemm_p_mode(a, 0, 1) == 2 && !getenv("POLUS_RING_RUNTIME_EPI")) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
+    if (polus_gemm_p_mode(a, 0, 1) == 2 && !polus_cfg().ring_runtime_epi) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
     return launch_ring<bf16_t, false, false, true>(a, 1, st);
 }
 
 int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st) {
-    if (!c_is_f32 && !a_ks && !b_ks && splits == 1 && !getenv("POLUS_RING_RUNTIME_EPI")) {
+    if (!c_is_f32 && !a_ks && !b_ks && splits == 1 && !polus_cfg().ring_runtime_epi) {
         switch (polus_gemm_p_mode(a, 0, 0)) {      // same epilogue classes as the persistent kernel
             case 0: return launch_ring<bf16_t, false, false, false, 0>(a, 1, st);
             case 1: return launch_ring<bf16_t, false, false, false, 1>(a, 1, st);

@@ -12,6 +12,30 @@ void polus_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* polus_last_error(void) { return g_err; }
+
+static PolusCfg g_cfg;
+static bool g_cfg_ready = false;
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+static void read_cfg() {
+    g_cfg.gemm_p = env_int("POLUS_GEMM_P", 0);
+    g_cfg.gemm_pp = env_int("POLUS_GEMM_PP", 0);
+    g_cfg.gemm_v1 = getenv("POLUS_GEMM_V1") != nullptr;
+    g_cfg.gemm_256 = getenv("POLUS_GEMM_256") != nullptr;
+    g_cfg.ring_runtime_epi = getenv("POLUS_RING_RUNTIME_EPI") != nullptr;
+    g_cfg.dw_ungrouped = getenv("POLUS_DW_UNGROUPED") != nullptr;
+    g_cfg.ablate = env_int("POLUS_GEMM_ABLATE", 0);
+    g_cfg.attn_waves = env_int("POLUS_ATTN_WAVES", 0);
+    g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
+    g_cfg_ready = true;
+}
+const PolusCfg& polus_cfg() {
+    if (!g_cfg_ready) read_cfg();
+    return g_cfg;
+}
+extern "C" int polus_reload_env(void) { read_cfg(); return POLUS_OK; }
 extern "C" int polus_abi_version(void) { return POLUS_ABI_VERSION; }
 
 extern "C" int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len) {

@@ -55,6 +55,17 @@ def _st():
     return _lib.current_stream()
 
 
+def set_env(name, value=None):
+    """Set (or, with None, unset) one of the library's POLUS_* tuning switches and make the library
+    re-read them: they are cached at load time (include/polus_hip.h polus_reload_env)."""
+    import os
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    check(_lib.load().polus_reload_env(), "polus_reload_env")
+
+
 def _req_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:

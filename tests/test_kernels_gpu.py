@@ -421,10 +421,10 @@ def test_gemm256_matches_reference_and_v1(ops, M, N, K, monkeypatch):
     o32 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     ops.gemm(a_t, b_t, o32)
     assert_close(host(o32), ref, 2e-5 * max(1, K / 64), "gemm256 f32 out")
-    monkeypatch.setenv("POLUS_GEMM_V1", "1")
+    ops.set_env("POLUS_GEMM_V1", "1")
     o1 = torch.empty_like(o32)
     ops.gemm(a_t, b_t, o1)
-    monkeypatch.delenv("POLUS_GEMM_V1")
+    ops.set_env("POLUS_GEMM_V1")
     assert_close(host(o32), host(o1), 1e-5, "gemm256 vs 128x128 kernel")
     # run-to-run bitwise identical (no atomics, fixed k order)
     o2 = torch.empty_like(o32)
@@ -497,10 +497,10 @@ def test_gemm_ring_dw_k_strided(ops, T, N, K, splits, monkeypatch):
         o2 = torch.empty_like(out)
         ops.gemm(dy_t, x_t, o2, a_layout=1, b_layout=1, split_k=sk)
         assert torch.equal(out, o2), "split-K reduction must be bitwise reproducible"
-        monkeypatch.setenv("POLUS_GEMM_V1", "1")
+        ops.set_env("POLUS_GEMM_V1", "1")
         o1 = torch.empty_like(out)
         ops.gemm(dy_t, x_t, o1, a_layout=1, b_layout=1, split_k=sk)
-        monkeypatch.delenv("POLUS_GEMM_V1")
+        ops.set_env("POLUS_GEMM_V1")
         assert_close(host(out), host(o1), 2e-5, "ring vs 128x128 kernel")
     # accumulate + alpha through the split-K reduce kernel
     base = r.standard_normal((N, K)).astype(np.float32)
@@ -521,10 +521,10 @@ def test_gemm_ring_mixed_layouts(ops, M, N, K, monkeypatch):
         out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
         ops.gemm(a_t, b_t, out, a_layout=al, b_layout=bl)
         assert_close(host(out), ref, TOL[dt], f"ring mixed {al}{bl}")
-        monkeypatch.setenv("POLUS_GEMM_V1", "1")
+        ops.set_env("POLUS_GEMM_V1", "1")
         o1 = torch.empty_like(out)
         ops.gemm(a_t, b_t, o1, a_layout=al, b_layout=bl)
-        monkeypatch.delenv("POLUS_GEMM_V1")
+        ops.set_env("POLUS_GEMM_V1")
         assert_close(host(out), host(o1), 1e-2, "ring vs 128x128")
 
 
@@ -565,14 +565,14 @@ def test_gemm_persistent_256x192(ops, M, N, K, monkeypatch):
     def both(**kw):
         outs = []
         for sel in ("2", "0"):
-            monkeypatch.setenv("POLUS_GEMM_P", sel)
+            ops.set_env("POLUS_GEMM_P", sel)
             out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
             kw2 = dict(kw)
             if kw2.get("aux") == "new":
                 kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
             ops.gemm(a_t, b_t, out, **kw2)
             outs.append((out, kw2.get("aux")))
-        monkeypatch.delenv("POLUS_GEMM_P")
+        ops.set_env("POLUS_GEMM_P")
         assert torch.equal(outs[0][0], outs[1][0]), "persistent kernel differs from the ring kernel"
         return outs[0]
 
@@ -588,6 +588,63 @@ def test_gemm_persistent_256x192(ops, M, N, K, monkeypatch):
     out, _ = both(bias=bias_t, resid=r_t, drop_p=0.25, seed=123)
     keep = host(ops.dropout_mask(123, 0.25, M * N)).astype(np.float64).reshape(M, N)
     assert_close(host(out), (base + bias) * keep / 0.75 + rounded(R, dt), tol, "dropout+resid")
+
+
+@pytest.mark.parametrize("tn", [256, 192])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (256, 256, 64), (256, 192, 128), (520, 456, 192), (1024, 2304, 320),
+                                   (768, 3072, 3072)])
+def test_gemm_pingpong_256wide(ops, tn, M, N, K):
+    """gemm_pp.hip (256 x 256 / 256 x 192 tile, two staggered wave groups): every epilogue mode, one /
+    two / three / many K-tiles (the three tail variants of the load schedule), interior and ragged
+    tiles, against the oracle arithmetic and bit-for-bit against the ring kernel (same MFMA k-order,
+    same epilogue)."""
+    r = rng(M + 7 * N + K + tn)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.1
+    bias, R, U = r.standard_normal(N), r.standard_normal((M, N)), r.standard_normal((M, N))
+    dt = torch.bfloat16
+    a_t, b_t, bias_t, r_t, u_t = dev(A, dt), dev(B, dt), dev(bias, torch.float32), dev(R, dt), dev(U, dt)
+    base = rounded(A, dt) @ rounded(B, dt).T
+    tol = TOL[dt]
+
+    def both(**kw):
+        outs = []
+        try:
+            for sel in (tn, -1):
+                ops.set_env("POLUS_GEMM_PP", sel)
+                out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+                kw2 = dict(kw)
+                if kw2.get("aux") == "new":
+                    kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+                ops.gemm(a_t, b_t, out, **kw2)
+                outs.append((out, kw2.get("aux")))
+        finally:
+            ops.set_env("POLUS_GEMM_PP")
+        assert torch.equal(outs[0][0], outs[1][0]), "ping-pong kernel differs from the ring kernel"
+        if outs[0][1] is not None and kw.get("aux") == "new":
+            assert torch.equal(outs[0][1], outs[1][1]), "ping-pong kernel: aux differs from the ring kernel"
+        return outs[0]
+
+    out, _ = both(bias=bias_t)
+    assert_close(host(out), base + bias, tol, "bias")
+    out, aux = both(bias=bias_t, aux="new", act="gelu", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(aux), base + bias, tol, "aux")
+    assert_close(host(out), ob.gelu(base + bias), tol, "gelu")
+    out, _ = both(bias=bias_t, resid=r_t)
+    assert_close(host(out), base + bias + rounded(R, dt), tol, "bias+resid")
+    out, _ = both(aux=u_t, act="gelu", flags=ops.GEMM_ACT_BWD)
+    assert_close(host(out), base * ob.gelu_grad(rounded(U, dt)), tol, "gelu bwd")
+    out, _ = both(bias=bias_t, resid=r_t, drop_p=0.25, seed=123)
+    keep = host(ops.dropout_mask(123, 0.25, M * N)).astype(np.float64).reshape(M, N)
+    assert_close(host(out), (base + bias) * keep / 0.75 + rounded(R, dt), tol, "dropout+resid")
+    # run-to-run bitwise identical
+    ops.set_env("POLUS_GEMM_PP", tn)
+    try:
+        o1, o2 = torch.empty((M, N), dtype=dt, device="cuda"), torch.empty((M, N), dtype=dt, device="cuda")
+        ops.gemm(a_t, b_t, o1, bias=bias_t)
+        ops.gemm(a_t, b_t, o2, bias=bias_t)
+        assert torch.equal(o1, o2)
+    finally:
+        ops.set_env("POLUS_GEMM_PP")
 
 
 def test_gelu_polynomial_epilogue_precision(ops):

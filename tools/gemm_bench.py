@@ -62,12 +62,12 @@ def main():
         }
         for vname, fn in variants.items():
             t3 = bench(fn, args.iters)
-            os.environ["POLUS_GEMM_256"] = "1"
+            ops.set_env("POLUS_GEMM_256", 1)
             t2 = bench(fn, args.iters)
-            del os.environ["POLUS_GEMM_256"]
-            os.environ["POLUS_GEMM_V1"] = "1"
+            ops.set_env("POLUS_GEMM_256")
+            ops.set_env("POLUS_GEMM_V1", 1)
             t1 = bench(fn, args.iters)
-            del os.environ["POLUS_GEMM_V1"]
+            ops.set_env("POLUS_GEMM_V1")
             rows.append((name, M, N, K, vname, fl / t3 / 1e12, t3 * 1e6, fl / t2 / 1e12, t2 * 1e6, fl / t1 / 1e12, t1 * 1e6))
         # dW shape: [N, K] = dY^T X, both K-strided, f32 out, split-K as the model uses it
         from polus_amd.layers import dw_split_k

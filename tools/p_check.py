@@ -28,7 +28,7 @@ for (M, N, K) in [(256, 192, 64), (512, 384, 128), (16384, 768, 768), (2048, 230
     for name, (kw, fn) in variants.items():
         outs = []
         for mode in ("0", "2"):
-            os.environ["POLUS_GEMM_P"] = mode
+            ops.set_env("POLUS_GEMM_P", mode)
             kw2 = dict(kw)
             f32 = kw2.pop("f32", False)
             c = torch.full((M, N), 0.5, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
