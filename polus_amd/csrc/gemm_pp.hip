@@ -23,18 +23,23 @@
 // global_load_lds_dwordx4 in 8 KiB pieces (one wave-instruction = 8 rows x 128 B, lane-linear, so the
 // bank swizzle sits on the SOURCE address: LDS chunk c of row r holds K-chunk c ^ ((r >> 1) & 7);
 // fragment reads apply the same XOR and every ds_read_b128 lane group hits 16 distinct 16-byte slots).
-// A piece = the 32-row slab q of both wave groups (rows wm*128 + 32q ..), read only in phase q;
-// B pieces = 64 rows each, read only in phase 0.  A region is refilled TWO phases after the phase that
-// read it (the other group reads half a phase later, and reads retire at the lgkmcnt(0) after
-// barrier (a)), with the data of the K-tile two ahead:
-//     phase 0 of tile t: A slab 2 and the last B piece of tile t+1      (2 loads per wave)
-//     phase 1          : A slab 3 of tile t+1                           (1)
-//     phase 2          : A slab 0 and B pieces 0..NB-3 of tile t+2      (NB-1)
-//     phase 3          : A slab 1 and B piece NB-2 of tile t+2          (2)
-// i.e. every byte is in flight for >= 4 phases (~2k cycles of MFMA time).  The only waits are counted:
-// before barrier (a) of phase 3 `vmcnt(NB+2)` (everything issued up to phase 0 has landed: all of tile
-// t+1's B and slabs 0-2), before barrier (a) of phase 2 `vmcnt(2NB+3)` (slab 3 of tile t).  Data is read
-// one phase after the wait + barrier that retired it.
+// A piece = the 32-row slab q of both wave groups (rows wm*128 + 32q ..), consumed by phase q;
+// B pieces = 64 rows each, consumed from phase 0 on.
+//
+// Inside an R section the fragment reads come first and the LDS-DMA issue after them, and the section
+// ends with lgkmcnt(0) BEFORE barrier (a): the LDS latency passes under the DMA issue instead of idling the
+// matrix pipe at the head of the M section (tools/pp_ablate.py: with the wait behind the barrier the
+// reads cost +10 us on a 54 us MFMA-only loop; reading the next phase's fragments underneath the MFMAs
+// cost +20 us).  The region a phase consumes is therefore free one phase later and is refilled then
+// with the data of the K-tile two ahead:
+//     phase 0 of tile t: A slab 3 (and B piece 3) of tile t+1
+//     phase P = 1..3   : A slab P-1 and B piece P-1 of tile t+2          (2 loads per wave and phase)
+// The R sections run at raised priority (s_setprio 2): their ~20 instructions share the SIMD's issue port with
+// the other group's MFMA stream, and left at equal priority they stretch past the M section they are
+// meant to hide under (-8 % kernel time; priority on the M sections instead is the slower way round).
+// i.e. every byte has >= 3 phases to land.  One counted wait per K-tile: `vmcnt(6)` at the end of phase
+// 3's R section (everything issued up to phase 0 has landed: all of tile t+1); data is read in an R
+// section that starts after the wait and a barrier every wave has passed.
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -56,7 +61,9 @@ template <int NT> struct PPCfg {
     static constexpr int SMEM = 2 * STAGE;
 };
 
-template <int NT, bool DROP, int MODE>
+// ABL (diagnostics, POLUS_GEMM_ABLATE): bit0 = no LDS-DMA inside the K loop, bit1 = no MFMA, bit2 = no fragment reads,
+// bit3 = raised priority for the M sections instead of the R sections
+template <int NT, bool DROP, int MODE, int ABL = 0>
 __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     typedef PPCfg<NT> C;
     constexpr int WN = C::WN, TN = C::TN, NB = C::NB, STAGE = C::STAGE;
@@ -110,20 +117,35 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Frag<bf16_t> bfr[NT][2], af[2][2];
+    Frag<bf16_t> bfr[NT][2], af[2][2];         // af[m-tile of the phase][k-half]
+    auto read_a = [&](int tile, int slab, int m) {
+        const unsigned char* st = smem + (tile & 1) * STAGE + a_off + (2 * slab + m) * 2048;
+        if (ABL & 4) { asm volatile("" : "+v"(af[m][0].v), "+v"(af[m][1].v)); return; }
+        af[m][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
+        af[m][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
+    };
+    auto read_b = [&](int tile, int nt) {
+        const unsigned char* st = smem + (tile & 1) * STAGE + b_off + nt * 2048;
+        if (ABL & 4) { asm volatile("" : "+v"(bfr[nt][0].v), "+v"(bfr[nt][1].v)); return; }
+        bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
+        bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
+    };
+    if (ABL & 4) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bfr[nt][0].v = (bf16x8)(bf16_t)0.5f; bfr[nt][1].v = (bf16x8)(bf16_t)0.25f; }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { af[m][0].v = (bf16x8)(bf16_t)0.5f; af[m][1].v = (bf16x8)(bf16_t)0.25f; }
+    }
 
-    // ---- prologue: all of tile 0, then what phases 2 and 3 of "tile -1" would have issued
+    // ---- prologue: all of tile 0, then what phases 1-3 of "tile -1" would have issued for tile 1
 #pragma unroll
     for (int q = 0; q < 4; ++q) load_a(0, q);
 #pragma unroll
     for (int b = 0; b < NB; ++b) load_b(0, b);
     if (nk > 1) {
-        load_a(1, 0);
 #pragma unroll
-        for (int b = 0; b + 2 < NB; ++b) load_b(1, b);
-        load_a(1, 1);
-        load_b(1, NB - 2);
-        vmcnt<NB + 1>();
+        for (int q = 0; q < 3; ++q) { load_a(1, q); load_b(1, q); }
+        vmcnt<6>();
     } else {
         vmcnt<0>();
     }
@@ -133,46 +155,37 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     // TAIL: 0 = tiles t+1 and t+2 exist, 1 = only t+1, 2 = last tile
     auto phase = [&](auto P_, auto TAIL_, int t) {
         constexpr int P = decltype(P_)::value, TAIL = decltype(TAIL_)::value;
-        const unsigned char* st = smem + (t & 1) * STAGE;
-        // R: loads two phases behind the reads that freed their destination
-        if (P == 0 && TAIL <= 1) { load_a(t + 1, 2); load_b(t + 1, NB - 1); }
-        if (P == 1 && TAIL <= 1) { load_a(t + 1, 3); }
-        if (P == 2 && TAIL == 0) {
-            load_a(t + 2, 0);
-#pragma unroll
-            for (int b = 0; b + 2 < NB; ++b) load_b(t + 2, b);
-        }
-        if (P == 3 && TAIL == 0) { load_a(t + 2, 1); load_b(t + 2, NB - 2); }
+        // R: this phase's fragments first -- their LDS latency passes under the LDS-DMA issue below --
+        // then the refill of what the previous phase's reads released
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(2);
         if (P == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 2048 + c0);
-                bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 2048 + c1);
-            }
+            for (int nt = 0; nt < NT; ++nt) read_b(t, nt);
         }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            af[m][0].v = *reinterpret_cast<const bf16x8*>(st + a_off + (2 * P + m) * 2048 + c0);
-            af[m][1].v = *reinterpret_cast<const bf16x8*>(st + a_off + (2 * P + m) * 2048 + c1);
+        read_a(t, P, 0);
+        read_a(t, P, 1);
+        if (!(ABL & 1)) {
+            if (P == 0 && TAIL <= 1) { load_a(t + 1, 3); if (NB == 4) load_b(t + 1, 3); }
+            if (P >= 1 && TAIL == 0) { load_a(t + 2, P - 1); load_b(t + 2, P - 1); }
         }
-        if (P == 2) {
-            if (TAIL == 0) vmcnt<2 * NB + 3>(); else if (TAIL == 1) vmcnt<NB + 4>(); else vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers: their LDS region is free
+        if (P == 3) {                                         // LDS-DMA data of the next K-tile has landed
+            if (TAIL == 0) vmcnt<6>(); else vmcnt<0>();
         }
-        if (P == 3) {
-            if (TAIL == 0) vmcnt<NB + 2>(); else if (TAIL == 1) vmcnt<1>();
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                if (ABL & 2) { asm volatile("" :: "v"(bfr[nt][0].v), "v"(bfr[nt][1].v), "v"(af[m][0].v), "v"(af[m][1].v)); continue; }
                 mma16(acc[2 * P + m][nt], bfr[nt][0], af[m][0]);
                 mma16(acc[2 * P + m][nt], bfr[nt][1], af[m][1]);
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (ABL & 8) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -193,11 +206,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
                                                  smem + wid * ((EpiCfg<WN>::BYTES + 255) / 256 * 256));
 }
 
-template <int NT, bool DROP, int MODE>
+template <int NT, bool DROP, int MODE, int ABL = 0>
 int launch_pp(const GemmArgs& a, hipStream_t st) {
     typedef PPCfg<NT> C;
     static bool attr_done = false;
-    auto kern = gemm_pp_kernel<NT, DROP, MODE>;
+    auto kern = gemm_pp_kernel<NT, DROP, MODE, ABL>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
@@ -211,6 +224,19 @@ int launch_pp(const GemmArgs& a, hipStream_t st) {
 
 template <int NT>
 int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
+    if (a.ablate && mode == 0) {
+        switch (a.ablate & 15) {
+            case 7: return launch_pp<NT, false, 0, 7>(a, st);
+            case 8: return launch_pp<NT, false, 0, 8>(a, st);
+            case 1: return launch_pp<NT, false, 0, 1>(a, st);
+            case 2: return launch_pp<NT, false, 0, 2>(a, st);
+            case 3: return launch_pp<NT, false, 0, 3>(a, st);
+            case 4: return launch_pp<NT, false, 0, 4>(a, st);
+            case 5: return launch_pp<NT, false, 0, 5>(a, st);
+            case 6: return launch_pp<NT, false, 0, 6>(a, st);
+            default: break;
+        }
+    }
     switch (mode) {
         case 0: return launch_pp<NT, false, 0>(a, st);
         case 1: return launch_pp<NT, false, 1>(a, st);
