@@ -13,8 +13,11 @@ Weak scaling: per-GPU batch fixed.  Rank 0 prints ONE JSON line.
 its launches are bracketed with HIP events during one extra instrumented step after the
 timed region; achieved = algorithmic FLOPs of those launches / their summed device time.
 `step_mfma_frac` is BASELINE.md's whole-step figure: samples/s/GPU x F_step(sample) / peak.
-`cpu_baseline` times the NumPy oracle's identical step (fwd + bwd + AdamW) on the host cores
-of this box, on a bounded sample (B=4): a reported baseline, not the target.
+`f32` is the same workload on the f32 engine (exact-f32 MFMA -- the reference computes in fp32), timed in
+the same run; `loss_at_step100` is BASELINE.json's loss@step100 for both engines (dropout 0).
+`cpu_baseline` times a torch-CPU eager fp32 restatement of the identical step (fwd + bwd + AdamW,
+oracle/bert_torch.py) on the host cores of this box, on a bounded sample (B=8, 3 + 5 steps): a reported
+baseline, not the target.
 """
 import argparse
 import json
@@ -51,35 +54,172 @@ def synth_batch(B, S, seed, vocab=VOCAB, C=N_LABELS):
     return ids, mask, np.zeros_like(ids), labels
 
 
-def cpu_baseline(S, L, H, A, I, seconds_budget=25.0):
-    """The oracle's train step (NumPy/OpenBLAS, f32) on this box's host cores."""
+def cpu_baseline(S, L, H, A, I, B=8, warm=3, timed=5):
+    """The same training step (forward, mean CE, backward, AdamW) as a torch-CPU eager fp32 restatement
+    (oracle/bert_torch.py, pinned to the NumPy oracle by tests/test_oracle_golden.py) on this box's host
+    cores: SURVEY.md §8(d) -- B=8, 3 warm-up + 5 timed steps, all cores."""
+    import torch
     from oracle import bert as ob
+    from oracle import bert_torch as bt
     from oracle import optim as oo
-    B = 4
+    torch.set_num_threads(os.cpu_count() or 1)
     cfg = ob.BertConfig(VOCAB, H, L, A, I, 512, 2)
     params = ob.init_params(cfg, seed=1234, dtype=np.float32)
     rng = np.random.Generator(np.random.PCG64(7))
-    hw = (np.clip(rng.standard_normal((N_LABELS, H)), -2, 2) * 0.02).astype(np.float32)
-    hb = np.zeros(N_LABELS, np.float32)
-    allp = dict(params); allp["head.w"] = hw; allp["head.b"] = hb
-    opt = oo.Adam(lr=5e-5, weight_decay=0.01, no_decay=[k for k in allp if oo.is_no_decay(k)])
+    params["head.w"] = (np.clip(rng.standard_normal((N_LABELS, H)), -2, 2) * 0.02).astype(np.float32)
+    params["head.b"] = np.zeros(N_LABELS, np.float32)
+    p = bt.to_torch(params, torch.float32)
+    opt = bt.Adam(lr=5e-5, weight_decay=0.01, no_decay=[k for k in params if oo.is_no_decay(k)])
 
     def step(seed):
         ids, mask, tt, labels = synth_batch(B, S, seed)
-        loss, _, cache = ob.token_classifier_fwd(allp, cfg, allp["head.w"], allp["head.b"], ids, mask, labels, tt)
-        opt.step(allp, ob.token_classifier_bwd(allp, cfg, allp["head.w"], cache))
-        return loss
+        return bt.train_step(p, cfg, opt, ids, mask, labels, tt)
 
-    step(0)  # warm-up
+    for k in range(warm):
+        step(k)
     t0 = time.perf_counter()
-    n = 0
-    while n < 3 or (time.perf_counter() - t0 < seconds_budget * 0.5 and n < 8):
-        step(1 + n)
-        n += 1
+    for k in range(timed):
+        step(warm + k)
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"NumPy oracle, f32, B={B} S={S} BERT-base L={L}, {n} timed steps after 1 warm-up "
-                      f"({dt:.1f} s), OpenBLAS threads = all cores"}
+    return {"value": round(B * timed / dt, 3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"torch-CPU eager fp32 restatement of the step (oracle/bert_torch.py), B={B} S={S} "
+                      f"BERT-base L={L}, {timed} timed steps after {warm} warm-up ({dt:.1f} s), "
+                      f"torch threads = {torch.get_num_threads()}"}
+
+
+def build_trainer(args, dtype, dropout, total_steps):
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import BertConfig, BertModel
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.schedulers import warmup_scheduler
+    from polus_amd.training import ClassifierTrainer
+    H, A, I, L = args.geom
+    cfg = BertConfig(vocab_size=VOCAB, hidden_size=H, num_hidden_layers=L, num_attention_heads=A,
+                     intermediate_size=I, max_position_embeddings=512,
+                     hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout)
+    model = BertModel(cfg, compute_dtype=dtype, num_labels=N_LABELS, seed=1234)
+    opt = AdamWeightDecay(learning_rate=warmup_scheduler(total_steps, 5e-5), weight_decay_rate=0.01)
+    trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy(grad_dtype=model.compute_dtype))
+    return model, trainer
+
+
+def device_batches(B, S, rank, dev, n=4, seed0=42):
+    import torch
+    out = []
+    for k in range(n):
+        ids, mask, tt, labels = synth_batch(B, S, seed0 + rank + 1000 * k)
+        out.append(({"input_ids": torch.from_numpy(ids).to(dev), "attention_mask": torch.from_numpy(mask).to(dev),
+                     "token_type_ids": torch.from_numpy(tt).to(dev)}, torch.from_numpy(labels).to(dev)))
+    return out
+
+
+def run_leg(args, dtype, steps, warmup, ctx, world, rank):
+    """W untimed + K timed steps of the headline workload on the `dtype` engine, then one instrumented
+    step (HIP events around every GEMM launch).  Returns the numbers of the JSON line for that engine."""
+    import torch
+    from polus_amd import comm, ops
+    H, A, I, L = args.geom
+    B, S = args.batch, args.seq
+    model, trainer = build_trainer(args, dtype, args.dropout, max(1000, steps + warmup))
+    if ctx.is_horovod_enabled():
+        trainer.broadcast_init_vars()
+    batches = device_batches(B, S, rank, model.arena.device)
+
+    def one_step(k):
+        x, y = batches[k % len(batches)]
+        return trainer.train_step(x, y)
+
+    first_loss = None
+    for k in range(warmup):
+        l = one_step(k)
+        if first_loss is None:
+            first_loss = float(l)
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        last = one_step(warmup + k)
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    last_loss = float(last)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=model.arena.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- instrumented step: HIP events (recorded on the launch stream) around every GEMM launch.
+    # Every rank takes the step -- it contains the gradient all-reduce -- only rank 0 records.  The dW
+    # GEMMs normally run beside the dX GEMMs on a side stream; an event pair would then time two kernels
+    # sharing the CUs, so this one step keeps everything on one stream (as the rocprof summaries under
+    # profiles/ do with POLUS_OVERLAP_DW=0).
+    roof, rec = None, []
+    if rank == 0:
+        ops.GEMM_PROFILE = rec
+    overlap = getattr(model, "overlap_dw", False)
+    model.overlap_dw = False
+    one_step(warmup + steps)
+    torch.cuda.synchronize()
+    model.overlap_dw = overlap
+    ops.GEMM_PROFILE = None
+    peak = PEAK_TFLOPS[dtype]
+    if rank == 0:
+        fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for (key, fl, e0, e1) in rec if key == "fwd"]
+        if fwd:
+            tsum, fsum = sum(t for t, _ in fwd), sum(f for _, f in fwd)
+            ach = fsum / tsum / 1e12
+            kern = ("gemm_pp_kernel<256 x 256 | 256 x 192, epilogue mode 0-3> (ping-pong; the ring kernel gemm_ring_kernel<bf16> where "
+                    "a launch would leave CUs idle)" if dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig> (exact-f32 MFMA 16x16x4)")
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "kernel": kern + " -- every K-contiguous Dense GEMM of the step: forward QKV, out-proj, FFN1, FFN2 and "
+                              "their input gradients dX = dY.W^T-shadow; the remaining GEMMs are the K-strided dW = dY^T.X",
+                    "launches": len(fwd), "avg_launch_us": round(tsum / len(fwd) * 1e6, 2),
+                    "flops_per_launch": fsum / len(fwd)}
+            tf = os.path.join(ROOT, "profiles", "r02_gemm_hbm_traffic.json")
+            if dtype == "bf16" and os.path.exists(tf) and (B, S, L, H) == (64, 256, 12, 768):
+                # NOT measured in this run: HBM bytes per launch of this kernel family from separate
+                # rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE), tools/hbm_traffic.py
+                roof["traffic_stored_profile"] = {"bytes_per_launch": json.load(open(tf))["bytes_per_launch"],
+                                                  "source": "profiles/r02_gemm_hbm_traffic.json (separate rocprofv3 --pmc passes; not measured in this run)"}
+            allg = [(e0.elapsed_time(e1) * 1e-3, fl) for (_, fl, e0, e1) in rec]
+            roof["all_gemm_tflops"] = round(sum(f for _, f in allg) / sum(t for t, _ in allg) / 1e12, 2)
+            roof["all_gemm_ms_per_step"] = round(sum(t for t, _ in allg) * 1e3, 3)
+    sps = world * B * steps / elapsed
+    fstep = f_step_per_sample(L, S, H)
+    out = {"value": round(sps, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "step_mfma_frac": round(sps / world * fstep / (peak * 1e12), 4), "mfma_peak_tflops": peak,
+           "step_tflops_per_gpu": round(sps / world * fstep / 1e12, 2),
+           "loss_first": round(first_loss, 5) if first_loss is not None else None, "loss_last": round(last_loss, 5)}
+    if roof:
+        out["roofline"] = roof
+    del trainer, model, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def loss_at_step100(args, rank):
+    """BASELINE.json's "loss@step100": 100 AdamW steps (warm-up 10 %, lr 5e-5, wd 0.01) of the headline shape
+    with dropout 0 -- TF's dropout stream cannot be matched, so parity runs have none -- from the same
+    initial weights over the same 8 recurring synthetic batches, on the f32 engine (exact-f32 MFMA; the engine
+    pinned to the float64 oracle, tests/test_model_gpu.py::test_loss_trajectory_100_steps and
+    tests/test_configs_gpu.py) and on the bf16 engine."""
+    import torch
+    out = {}
+    for dtype in ("f32", "bf16"):
+        model, trainer = build_trainer(args, dtype, 0.0, 100)
+        model.deterministic = True
+        batches = device_batches(args.batch, args.seq, rank, model.arena.device, n=8, seed0=100)
+        curve = [float(trainer.train_step(*batches[s % 8])) for s in range(100)]
+        out[dtype] = round(curve[-1], 5)
+        out[dtype + "_step1"] = round(curve[0], 5)
+        del trainer, model, batches
+        torch.cuda.empty_cache()
+    out["abs_diff"] = round(abs(out["bf16"] - out["f32"]), 5)
+    out["config"] = "dropout 0, deterministic reductions, same weights and batches for both engines"
+    return out
 
 
 def main():
@@ -94,16 +234,13 @@ def main():
     ap.add_argument("--large", action="store_true", help="BERT-large instead of BERT-base")
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden and attention dropout (HF BERT default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the reference-precision (f32 engine) leg")
+    ap.add_argument("--no-loss100", action="store_true", help="skip the 2 x 100-step loss@step100 runs")
     args = ap.parse_args()
 
     import torch
-    from polus_amd import comm, ops
+    from polus_amd import comm
     from polus_amd.context import PolusContext
-    from polus_amd.losses import SparseCategoricalCrossentropy
-    from polus_amd.models import BertConfig, BertModel
-    from polus_amd.optimizers import AdamWeightDecay
-    from polus_amd.schedulers import warmup_scheduler
-    from polus_amd.training import ClassifierTrainer
 
     ctx = PolusContext()           # joins the torchrun rendezvous when WORLD_SIZE > 1
     world, rank = comm.size(), comm.rank()
@@ -115,97 +252,27 @@ def main():
         torch.cuda.set_device(0)
 
     if args.large:
-        H, A, I, L = 1024, 16, 4096, args.layers if args.layers != 12 else 24
+        args.geom = (1024, 16, 4096, args.layers if args.layers != 12 else 24)
     else:
-        H, A, I, L = 768, 12, 3072, args.layers
+        args.geom = (768, 12, 3072, args.layers)
+    H, A, I, L = args.geom
     B, S = args.batch, args.seq
-    cfg = BertConfig(vocab_size=VOCAB, hidden_size=H, num_hidden_layers=L, num_attention_heads=A,
-                     intermediate_size=I, max_position_embeddings=512,
-                     hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout)
-    model = BertModel(cfg, compute_dtype=args.dtype, num_labels=N_LABELS, seed=1234)
-    total_steps = max(1000, args.steps + args.warmup)
-    opt = AdamWeightDecay(learning_rate=warmup_scheduler(total_steps, 5e-5), weight_decay_rate=0.01)
-    loss_fn = SparseCategoricalCrossentropy(grad_dtype=model.compute_dtype)
-    trainer = ClassifierTrainer(model, opt, loss_fn)
-    if ctx.is_horovod_enabled():
-        trainer.broadcast_init_vars()
 
-    dev = model.arena.device
-    batches = []
-    for k in range(4):
-        ids, mask, tt, labels = synth_batch(B, S, 42 + rank + 1000 * k)
-        batches.append(({"input_ids": torch.from_numpy(ids).to(dev), "attention_mask": torch.from_numpy(mask).to(dev),
-                         "token_type_ids": torch.from_numpy(tt).to(dev)}, torch.from_numpy(labels).to(dev)))
-
-    def one_step(k):
-        x, y = batches[k % len(batches)]
-        return trainer.train_step(x, y)
-
-    first_loss = None
-    for k in range(args.warmup):
-        l = one_step(k)
-        if first_loss is None:
-            first_loss = float(l)
-    torch.cuda.synchronize()
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        last = one_step(args.warmup + k)
-    torch.cuda.synchronize()
-    comm.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    last_loss = float(last)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- instrumented step: HIP events around every launch of the dominant kernel
-    # (every rank takes the step -- it contains the gradient all-reduce -- only rank 0 records)
-    roof = None
-    rec = []
-    # The dW GEMMs normally run beside the dX GEMMs on a side stream; events around a launch would
-    # then time two kernels sharing the CUs, so this one step keeps everything on one stream (as
-    # the rocprof summaries under profiles/ do with POLUS_OVERLAP_DW=0).
-    if rank == 0:
-        ops.GEMM_PROFILE = rec
-    overlap = getattr(model, "overlap_dw", False)
-    model.overlap_dw = False
-    one_step(args.warmup + args.steps)
-    torch.cuda.synchronize()
-    model.overlap_dw = overlap
-    ops.GEMM_PROFILE = None
-    if rank == 0:
-        fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for (key, fl, e0, e1) in rec if key == "fwd"]
-        if fwd:
-            tsum, fsum = sum(t for t, _ in fwd), sum(f for _, f in fwd)
-            ach = fsum / tsum / 1e12
-            peak = PEAK_TFLOPS[args.dtype]
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
-                    "kernel": ("gemm_ring_kernel<bf16, K-contig, K-contig, epilogue mode 0-3>" if args.dtype == "bf16" else "gemm_kernel<f32, K-contig, K-contig>")
-                              + " (every K-contiguous Dense GEMM of the step: forward QKV, out-proj, FFN1, FFN2 and their"
-                                " input gradients dX = dY.W^T-shadow; the remaining GEMMs are the K-strided dW = dY^T.X)",
-                    "launches": len(fwd), "avg_launch_us": round(tsum / len(fwd) * 1e6, 2),
-                    "flops_per_launch": fsum / len(fwd)}
-            tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-            if args.dtype == "bf16" and os.path.exists(tf) and (B, S, L, H) == (64, 256, 12, 768):
-                # HBM bytes per launch of this kernel from separate rocprofv3 --pmc passes (FETCH_SIZE x2
-                # gfx950 correction, WRITE_SIZE) reduced by tools/hbm_traffic.py, see profiles/README.md
-                roof["traffic"] = json.load(open(tf))["bytes_per_launch"]
-            allg = [(e0.elapsed_time(e1) * 1e-3, fl) for (_, fl, e0, e1) in rec]
-            roof["all_gemm_tflops"] = round(sum(f for _, f in allg) / sum(t for t, _ in allg) / 1e12, 2)
-            roof["all_gemm_ms_per_step"] = round(sum(t for t, _ in allg) * 1e3, 3)
+    head = run_leg(args, args.dtype, args.steps, args.warmup, ctx, world, rank)
+    # the reference computes in fp32 throughout (polus/models.py:197): the same workload on the f32 engine
+    # (exact-f32 MFMA), timed in the same run on every rank; fewer steps, it is ~6x slower
+    f32 = None
+    if args.dtype == "bf16" and not args.no_f32_leg:
+        f32 = run_leg(args, "f32", max(3, min(args.steps, 6)), 2, ctx, world, rank)
+    l100 = None
+    if world == 1 and not args.no_loss100 and (B, S) == (64, 256) and not args.large:
+        l100 = loss_at_step100(args, rank)
 
     if rank == 0:
-        sps = world * B * args.steps / elapsed
-        fstep = f_step_per_sample(L, S, H)
         out = {
-            "metric": "train samples/sec BioBERT-base NER seq256", "value": round(sps, 2), "unit": "samples/s",
+            "metric": "train samples/sec BioBERT-base NER seq256", "value": head["value"], "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BERT-{'large' if args.large else 'base'} (L={L},H={H},A={A},I={I},V={VOCAB}) "
                                    f"token classification C={N_LABELS}, seq_len={S}, {B} samples/GPU "
@@ -213,12 +280,17 @@ def main():
                                    f"dropout {args.dropout} (hidden + attention), random-init weights",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "grad_allreduce": "bucketed RCCL all-reduce (f32, 64 MB buckets) overlapped with backward" if world > 1 else "none"},
-            "step_mfma_frac": round(sps / world * fstep / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
-            "step_tflops_per_gpu": round(sps / world * fstep / 1e12, 2),
-            "loss_first": round(first_loss, 5) if first_loss is not None else None, "loss_last": round(last_loss, 5),
+            "step_mfma_frac": head["step_mfma_frac"], "step_tflops_per_gpu": head["step_tflops_per_gpu"],
+            "loss_first": head["loss_first"], "loss_last": head["loss_last"],
         }
-        if roof:
-            out["roofline"] = roof
+        if "roofline" in head:
+            out["roofline"] = head["roofline"]
+        if f32 is not None:
+            out["f32"] = dict(f32, unit="samples/s", dtype="f32",
+                              note="same workload on the f32 engine (exact-f32 MFMA, the reference's arithmetic type); "
+                                   "step_mfma_frac and roofline.frac are against the 157.3 TFLOP/s fp32 matrix peak")
+        if l100 is not None:
+            out["loss_at_step100"] = l100
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, L, H, A, I)
         print(json.dumps(out), flush=True)

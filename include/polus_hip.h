@@ -206,6 +206,12 @@ int polus_crf_viterbi(const float* potentials, const int32_t* lengths, const flo
 /* ---- argmax over the last axis (PolusClassifier.inference, polus/models.py:148-150) */
 int polus_argmax(const float* x, long ldx, int32_t* out, int rows, int C, void* stream);
 
+/* ---- confusion matrix of the validation path (polus/metrics.py:51-66, tf.math.confusion_matrix):
+ * cm[row_idx[i]][col_idx[i]] += 1 for i < n; cm is int32 [C, C] on the device and is ACCUMULATED into
+ * (zero it to start); indices outside [0, C) are ignored; C <= 128.  Integer atomics: exact. */
+int polus_confusion_matrix(const int32_t* row_idx, const int32_t* col_idx, int64_t n, int C,
+                           int32_t* cm, void* stream);
+
 /* ---- optimizer (optimizer.apply_gradients, polus/training.py:191): Keras Adam /
  * HF AdamWeightDecay over a flat f32 arena.  `seg` is a device table of int64 triples
  * (begin, end, flags) covering [0,n) in chunks; flags bit0 = apply weight decay,
@@ -216,11 +222,16 @@ int polus_adam_step(float* p, const float* g, float* m, float* v, void* shadow_b
                     const int64_t* seg, int n_seg, int64_t n,
                     float lr, float lr_t, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, const float* clip_scale, void* stream);
-/* sum of squares of g[0..n) -> *out (deterministic two-stage); then
- * polus_clip_scale writes min(1, clip_norm / sqrt(*sqnorm * grad_scale^2)) */
+/* sum of squares of g[0..n) -> *out (deterministic two-stage); polus_sqnorm_segments sums only the
+ * windows [seg[3k], seg[3k+1]) of g (the polus_adam_step segment table: the variables actually being
+ * updated; workspace >= 4096 bytes); then polus_clip_scale writes
+ * min(1, clip_norm / sqrt(sum_k sqnorm[k] * grad_scale^2)) -- tf.clip_by_global_norm over n_terms partial
+ * sums (one per parameter arena). */
 size_t polus_sqnorm_workspace_bytes(int64_t n);
 int polus_sqnorm(const float* g, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
-int polus_clip_scale(const float* sqnorm, float grad_scale, float clip_norm, float* out_scale, void* stream);
+int polus_sqnorm_segments(const float* g, const int64_t* seg, int n_seg, float* out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int polus_clip_scale(const float* sqnorm, int n_terms, float grad_scale, float clip_norm, float* out_scale, void* stream);
 /* f32 -> bf16 copy (shadow weights refresh after load / broadcast) and bf16/f32 casts */
 int polus_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
 /* dst[cols][rows] = src[rows][cols]^T for bf16 (transposed weight shadow read by dX = dY . W) */

@@ -323,3 +323,23 @@ def golden_setup(cfg, n_classes, dtype=np.float64):
             params[k] = 0.05 * rng.standard_normal(params[k].shape)
     params = {k: v.astype(dtype) for k, v in params.items()}
     return params, head_w.astype(dtype), head_b.astype(dtype)
+
+
+# ----------------------------------------------------------------------------- HF pooler
+
+def pooler_fwd(last_hidden, w, b):
+    """HF BertPooler (transformers modeling_bert.py:451-463; what the reference reads as
+    `pooler_output` from an UNSPLIT TFBertModel, polus/data.py:526-543): tanh(h[:, 0] W^T + b).
+    TFBertSplited returns the raw slice instead (polus/models.py:215-216, bert_fwd's second output)."""
+    cls = last_hidden[:, 0, :]
+    pooled = np.tanh(cls @ w.T + b)
+    return pooled, (cls, pooled)
+
+
+def pooler_bwd(dpooled, w, cache, seq_len):
+    """-> (d last_hidden [B,S,H], dW, db)."""
+    cls, pooled = cache
+    du = dpooled * (1.0 - pooled * pooled)
+    dlast = np.zeros((cls.shape[0], seq_len, cls.shape[1]), dtype=cls.dtype)
+    dlast[:, 0, :] = du @ w
+    return dlast, du.T @ cls, du.sum(0)

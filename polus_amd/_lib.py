@@ -52,12 +52,14 @@ SIGNATURES = {
     "polus_crf_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_crf_nll": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "polus_crf_viterbi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "polus_argmax": (_i, [_vp, _l, _vp, _i, _i, _vp]),
     "polus_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64,
                              _f, _f, _f, _f, _f, _f, _f, _vp, _vp]),
     "polus_sqnorm_workspace_bytes": (_sz, [_i64]),
     "polus_sqnorm": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
-    "polus_clip_scale": (_i, [_vp, _f, _f, _vp, _vp]),
+    "polus_sqnorm_segments": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "polus_clip_scale": (_i, [_vp, _i, _f, _f, _vp, _vp]),
     "polus_cast": (_i, [_i, _vp, _i, _vp, _i64, _vp]),
     "polus_scale": (_i, [_vp, _f, _i64, _vp]),
     "polus_act_bwd": (_i, [_i, _vp, _vp, _vp, _i64, _i, _vp]),

@@ -37,6 +37,10 @@ def hf_state_to_params(state, num_layers):
         p[o + "qkv.b"] = np.concatenate([st[q + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], 0)
         for hf, ours in HF_LAYER_MAP:
             p[o + ours] = st[q + hf]
+    if "pooler.dense.weight" in st:
+        p["pooler.w"], p["pooler.b"] = st["pooler.dense.weight"], st["pooler.dense.bias"]
+    if "classifier.weight" in state:
+        p["head.w"], p["head.b"] = np.asarray(state["classifier.weight"]), np.asarray(state["classifier.bias"])
     return p
 
 
@@ -54,7 +58,7 @@ def read_local_hf_checkpoint(path):
     return cfg, hf_state_to_params(state, cfg["num_hidden_layers"])
 
 
-def load_bert_from_local(path, compute_dtype="bf16", num_labels=None):
+def load_bert_from_local(path, compute_dtype="bf16", num_labels=None, add_pooling_layer=False):
     from .models import BertConfig, BertModel
     if not os.path.isdir(path):
         raise FileNotFoundError(f"'{path}' is not a local directory: checkpoints cannot be fetched by name (no network)")
@@ -65,7 +69,7 @@ def load_bert_from_local(path, compute_dtype="bf16", num_labels=None):
                      layer_norm_eps=c.get("layer_norm_eps", 1e-12),
                      hidden_dropout_prob=c.get("hidden_dropout_prob", 0.1),
                      attention_probs_dropout_prob=c.get("attention_probs_dropout_prob", 0.1), _name_or_path=path)
-    model = BertModel(cfg, compute_dtype=compute_dtype, num_labels=num_labels)
+    model = BertModel(cfg, compute_dtype=compute_dtype, num_labels=num_labels, add_pooling_layer=add_pooling_layer)
     model.load_numpy_params(params)
     return model
 
@@ -75,3 +79,57 @@ def load_weights(model, path):
     z = np.load(path if path.endswith(".npz") else path + ".npz", allow_pickle=False)
     model.set_weights([z[f"weight{i}"] for i in range(len(z.files))])
     return model
+
+
+# ------------------------------------------------------------------------------------ resume state
+def save_training_state(trainer, path):
+    """Everything a run needs to continue bit-for-bit after a restart, which the reference's
+    SaveModelCallback does not keep (polus/callbacks.py:264-313 saves weights only): the f32 master
+    parameters of every arena the trainer updates, the Adam moments, the optimizer's iteration count
+    (the learning-rate schedule's argument), the trainer's step / micro-step counters and the models'
+    dropout counters.  One `<path>.state.npz`; written by rank 0's caller."""
+    arenas = trainer._arenas()
+    opt = trainer.optimizer
+    out = {"n_arenas": np.int64(len(arenas)), "iterations": np.int64(getattr(opt, "iterations", 0)),
+           "step_counter": np.int64(trainer.step_counter), "micro": np.int64(getattr(trainer, "step_counter_micro", 0)),
+           "dropout_step": np.int64(getattr(trainer.model, "dropout_step", 0))}
+    for i, a in enumerate(arenas):
+        out[f"a{i}.params"] = a.params.detach().cpu().numpy()
+        if hasattr(opt, "_slots"):
+            m, v = opt._slots(a)
+            out[f"a{i}.m"], out[f"a{i}.v"] = m.detach().cpu().numpy(), v.detach().cpu().numpy()
+        if getattr(trainer, "grad_accum_steps", 1) > 1:
+            out[f"a{i}.grads"] = a.grads.detach().cpu().numpy()      # a partially accumulated step
+    p = path if path.endswith(".state.npz") else path + ".state.npz"
+    np.savez(p, **out)
+    return p
+
+
+def load_training_state(trainer, path):
+    """Inverse of save_training_state on a trainer built the same way (same model geometry and dtype)."""
+    import torch
+    p = path if path.endswith(".state.npz") else path + ".state.npz"
+    z = np.load(p, allow_pickle=False)
+    arenas = trainer._arenas()
+    if int(z["n_arenas"]) != len(arenas):
+        raise ValueError(f"{p}: saved from {int(z['n_arenas'])} parameter arenas, this trainer has {len(arenas)}")
+    opt = trainer.optimizer
+    for i, a in enumerate(arenas):
+        w = z[f"a{i}.params"]
+        if w.shape[0] != a.params.numel():
+            raise ValueError(f"{p}: arena {i} holds {w.shape[0]} parameters, the model has {a.params.numel()}")
+        a.params.copy_(torch.from_numpy(w))
+        a.refresh_shadow()
+        if f"a{i}.m" in z.files and hasattr(opt, "_slots"):
+            m, v = opt._slots(a)
+            m.copy_(torch.from_numpy(z[f"a{i}.m"]))
+            v.copy_(torch.from_numpy(z[f"a{i}.v"]))
+        if f"a{i}.grads" in z.files:
+            a.grads.copy_(torch.from_numpy(z[f"a{i}.grads"]))
+    if hasattr(opt, "iterations"):
+        opt.iterations = int(z["iterations"])
+    trainer.step_counter = int(z["step_counter"])
+    trainer.step_counter_micro = int(z["micro"])
+    if hasattr(trainer.model, "dropout_step"):
+        trainer.model.dropout_step = int(z["dropout_step"])
+    return trainer

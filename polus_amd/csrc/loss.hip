@@ -262,6 +262,34 @@ extern "C" int polus_sigmoid_xent(int dtype, const float* logits, long ldl, cons
     return POLUS_OK;
 }
 
+// cm[r[i]][c[i]] += 1 for i < n (int32, exact): per-workgroup histogram in LDS, one atomic per non-zero cell
+__global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restrict__ r, const int32_t* __restrict__ c,
+                                                        int64_t n, int C, int32_t* __restrict__ cm) {
+    extern __shared__ int hist[];
+    const int cells = C * C;
+    for (int k = threadIdx.x; k < cells; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int a = r[i], b = c[i];
+        if ((unsigned)a < (unsigned)C && (unsigned)b < (unsigned)C) atomicAdd(&hist[a * C + b], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < cells; k += blockDim.x)
+        if (hist[k]) atomicAdd(&cm[k], hist[k]);
+}
+
+extern "C" int polus_confusion_matrix(const int32_t* row_idx, const int32_t* col_idx, int64_t n, int C,
+                                      int32_t* cm, void* stream) {
+    POLUS_REQUIRE(row_idx && col_idx && cm && n >= 0 && C > 0 && C <= 128, "polus_confusion_matrix: bad arguments (0 < C <= 128)");
+    if (n == 0) return POLUS_OK;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(256), (size_t)C * C * sizeof(int), static_cast<hipStream_t>(stream),
+                       row_idx, col_idx, n, C, cm);
+    POLUS_CHECK_LAUNCH("polus_confusion_matrix");
+    return POLUS_OK;
+}
+
 extern "C" int polus_argmax(const float* x, long ldx, int32_t* out, int rows, int C, void* stream) {
     POLUS_REQUIRE(x && out && rows > 0 && C > 0 && ldx >= C, "polus_argmax: bad arguments");
     hipLaunchKernelGGL(argmax_kernel, dim3((rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, out, rows, C);

@@ -439,22 +439,23 @@ __global__ __launch_bounds__(LN_THREADS) void embed_scatter_owner_kernel(const f
                                                                   float* __restrict__ gword, int rows, int H, int vocab) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
-        const int id = ids[row];
+        // duplicates are found on the CLAMPED id: two different out-of-range ids land on the same table row
+        auto clampid = [vocab](int v) { return v < 0 ? 0 : (v >= vocab ? vocab - 1 : v); };
+        const int cid = clampid(ids[row]);
         bool dup = false;
         for (int j0 = 0; j0 < row && !dup; j0 += 64) {
             int j = j0 + lane;
-            bool hit = (j < row) && (ids[j] == id);
+            bool hit = (j < row) && (clampid(ids[j]) == cid);
             dup = __any(hit);
         }
         if (dup) continue;  // wave-uniform
-        int cid = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         float* dst = gword + (long)cid * H;
         for (int c0 = 0; c0 < H; c0 += 64 * 4) {  // 256-feature slabs held in registers
             int col = c0 + lane * 4;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
             for (int j0 = row; j0 < rows; j0 += 64) {
                 int j = j0 + lane;
-                unsigned long long m = __ballot((j < rows) && (ids[j] == id));
+                unsigned long long m = __ballot((j < rows) && (clampid(ids[j]) == cid));
                 while (m) {
                     int b = __ffsll((long long)m) - 1;
                     m &= m - 1;

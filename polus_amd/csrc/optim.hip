@@ -84,6 +84,21 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// sum of squares over the windows [seg[3k], seg[3k+1]) of g: block b takes segments b, b + grid, ...
+__global__ __launch_bounds__(256) void sqnorm_seg_kernel(const float* __restrict__ g, const int64_t* __restrict__ seg, int n_seg,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int k = blockIdx.x; k < n_seg; k += gridDim.x) {
+        const int64_t b = seg[3 * k], e = seg[3 * k + 1];
+        for (int64_t i = b + threadIdx.x; i < e; i += 256) s += g[i] * g[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void sqnorm_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
     __shared__ float red[256];
     float s = 0.f;
@@ -97,8 +112,10 @@ __global__ void sqnorm_final_kernel(const float* __restrict__ partial, int n, fl
     }
 }
 
-__global__ void clip_scale_kernel(const float* __restrict__ sq, float gscale, float clip, float* __restrict__ out) {
-    float norm = sqrtf(*sq) * fabsf(gscale);
+__global__ void clip_scale_kernel(const float* __restrict__ sq, int n, float gscale, float clip, float* __restrict__ out) {
+    float t = 0.f;
+    for (int k = 0; k < n; ++k) t += sq[k];
+    float norm = sqrtf(t) * fabsf(gscale);
     *out = clip / fmaxf(norm, clip);  // tf.clip_by_global_norm: scale = clip / max(norm, clip)
 }
 
@@ -142,9 +159,22 @@ extern "C" int polus_sqnorm(const float* g, int64_t n, float* out, void* workspa
     return POLUS_OK;
 }
 
-extern "C" int polus_clip_scale(const float* sqnorm, float grad_scale, float clip_norm, float* out_scale, void* stream) {
-    POLUS_REQUIRE(sqnorm && out_scale && clip_norm > 0.f, "polus_clip_scale: bad arguments");
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), sqnorm, grad_scale, clip_norm, out_scale);
+extern "C" int polus_sqnorm_segments(const float* g, const int64_t* seg, int n_seg, float* out,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    POLUS_REQUIRE(g && seg && out && n_seg > 0, "polus_sqnorm_segments: bad arguments");
+    const int blocks = n_seg < 1024 ? n_seg : 1024;
+    if (!workspace || workspace_bytes < (size_t)1024 * sizeof(float)) { polus_set_error("polus_sqnorm_segments: workspace too small"); return POLUS_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sqnorm_seg_kernel, dim3(blocks), dim3(256), 0, st, g, seg, n_seg, static_cast<float*>(workspace));
+    POLUS_CHECK_LAUNCH("polus_sqnorm_segments(partial)");
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, static_cast<const float*>(workspace), blocks, out);
+    POLUS_CHECK_LAUNCH("polus_sqnorm_segments(final)");
+    return POLUS_OK;
+}
+
+extern "C" int polus_clip_scale(const float* sqnorm, int n_terms, float grad_scale, float clip_norm, float* out_scale, void* stream) {
+    POLUS_REQUIRE(sqnorm && out_scale && clip_norm > 0.f && n_terms > 0, "polus_clip_scale: bad arguments");
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), sqnorm, n_terms, grad_scale, clip_norm, out_scale);
     POLUS_CHECK_LAUNCH("polus_clip_scale");
     return POLUS_OK;
 }

@@ -187,7 +187,8 @@ class Dense(Layer):
         self._x = x2
         return y.view(*lead, self.units)
 
-    def backward(self, dy, accumulate=False, need_dx=True):
+    def backward(self, dy, accumulate=False, need_dx=True, dx_resid=None):
+        """dx_resid [rows, in] (row stride free): added to dX in the GEMM epilogue."""
         x = self._x
         dy2 = dy.reshape(-1, self.units)
         if dy2.dtype != x.dtype:  # f32 dlogits of an f32-output layer in bf16 mode
@@ -206,7 +207,10 @@ class Dense(Layer):
         if not need_dx:
             return None
         dx = self._buf("dx", (rows, self.in_features), x.dtype, x.device)
-        gemm_dx(dy2, self.w, dx)
+        if dx_resid is not None:
+            gemm_dx(dy2, self.w, dx, resid=dx_resid)
+        else:
+            gemm_dx(dy2, self.w, dx)
         return dx
 
 

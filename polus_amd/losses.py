@@ -12,6 +12,8 @@ from .tensor import DeviceScalar, to_device
 
 
 class _XentBase:
+    RING = 256
+
     def __init__(self, grad_dtype=None):
         self.grad_dtype = grad_dtype
         self._bufs = {}
@@ -25,8 +27,12 @@ class _XentBase:
         key = (tuple(l2.shape), gd)
         if self._bufs.get("key") != key:
             self._bufs = {"key": key, "d": torch.empty(l2.shape, dtype=gd, device=l2.device),
-                          "loss": torch.empty(1, dtype=torch.float32, device=l2.device)}
-        return l2, self._bufs["d"], self._bufs["loss"]
+                          "ring": torch.empty(self.RING, dtype=torch.float32, device=l2.device), "k": 0}
+        # every call hands out its own scalar: a loss kept from step k still reads step k's value after later
+        # steps (the reference returns independent tf tensors); the ring wraps after RING steps
+        k = self._bufs["k"]
+        self._bufs["k"] = (k + 1) % self.RING
+        return l2, self._bufs["d"], self._bufs["ring"][k:k + 1]
 
     def backward(self, accumulate=False):
         return self._dlogits

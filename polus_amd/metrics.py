@@ -1,7 +1,8 @@
 """polus/metrics.py drop-in: IMetric protocol, int32 confusion-matrix accumulation, macro-F1
-in float64 with divide_no_nan.  Eval-only bookkeeping on a C x C matrix (SURVEY.md §2 row 12:
-out of scope as compute), kept on the host in NumPy; predictions arrive as device or host
-arrays."""
+in float64 with divide_no_nan.  Predictions that arrive as device tensors (the inference kernels'
+int32 output) are counted where they are -- one `polus_confusion_matrix` launch per batch into a
+C x C int32 matrix in HBM, no device-to-host copy per validation step -- and only the C x C counts
+come to the host in `evaluate()`; host arrays (the gathered tuples of other ranks) are counted in NumPy."""
 import numpy as np
 
 
@@ -48,7 +49,17 @@ class IConfusionMatrixTF(IMetric):
         self.reset()
 
     def _samples_from_batch(self, samples):
-        self.confusion_matrix += self._build_confusion_matrix(*samples)
+        y_true, y_pred = samples
+        if getattr(y_true, "is_cuda", False) and getattr(y_pred, "is_cuda", False) and self.num_classes <= 128:
+            import torch
+            from . import ops
+            if self._dev_cm is None:
+                self._dev_cm = torch.zeros((self.num_classes, self.num_classes), dtype=torch.int32, device=y_true.device)
+            a = y_true.reshape(-1).to(torch.int32).contiguous()
+            b = y_pred.reshape(-1).to(torch.int32).contiguous()
+            ops.confusion_matrix(a, b, self._dev_cm)
+            return
+        self._host_cm += self._build_confusion_matrix(y_true, y_pred)
 
     def _build_confusion_matrix(self, y_true, y_pred):
         """tf.math.confusion_matrix: rows = first argument (polus/metrics.py:51-59)."""
@@ -56,8 +67,16 @@ class IConfusionMatrixTF(IMetric):
         np.add.at(cm, (_np(y_true).reshape(-1).astype(np.int64), _np(y_pred).reshape(-1).astype(np.int64)), 1)
         return cm
 
+    @property
+    def confusion_matrix(self):
+        """The counts so far (host int32 [C, C]); reading it synchronises with the device side."""
+        if self._dev_cm is None:
+            return self._host_cm
+        return self._host_cm + self._dev_cm.cpu().numpy()
+
     def reset(self):
-        self.confusion_matrix = np.zeros((self.num_classes, self.num_classes), np.int32)
+        self._host_cm = np.zeros((self.num_classes, self.num_classes), np.int32)
+        self._dev_cm = None
 
 
 def _divide_no_nan(a, b):

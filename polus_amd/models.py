@@ -9,6 +9,8 @@ into one [3H, H] matrix.
 """
 import json
 import os
+import sys
+from functools import wraps
 
 import numpy as np
 import torch
@@ -16,9 +18,62 @@ import torch
 from . import _lib, ops
 from .layers import CRF, Dense, Dropout, Flatten, Layer, dense_bwd_params_group, gemm_dx
 from .tensor import ParamArena, to_device, device
+from .utils import complex_json_deserializer, complex_json_serializer, flatten_dict, merge_dicts
 
 COMPUTE_DTYPES = {"f32": torch.float32, "float32": torch.float32, torch.float32: torch.float32,
                   "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, torch.bfloat16: torch.bfloat16}
+
+
+def load_model(file_name_w_ext, change_config={}, external_module=None):
+    """polus/models.py:18-50: rebuild a saved model from `<name>.cfg` (JSON written by SavableModel.save:
+    the keyword arguments of its @from_config builder + `func_name`), replay the build-time sample of
+    `<name>.init` if present, then load the weights (`weight0..N` in get_weights() order; `<name>.npz`
+    here, `<name>.h5` in the reference -- h5py is not in this image).  The builder is looked up in
+    `external_module` or in this module."""
+    file_name = os.path.splitext(file_name_w_ext)[0]
+    with open(file_name_w_ext, "r") as f:
+        cfg = complex_json_deserializer(json.load(f))
+    cfg["model"] = merge_dicts(cfg.get("model", {}), change_config)
+    module = external_module if external_module is not None else sys.modules[__name__]
+    model = getattr(module, cfg["func_name"])(**cfg)
+    if os.path.exists(file_name + ".init.npz"):
+        z = np.load(file_name + ".init.npz", allow_pickle=False)
+        spec = json.loads(str(z["__spec__"]))
+        args = [z[k] for k in spec["args"]]
+        kwargs = {k: z[v] for k, v in spec["kwargs"].items()}
+        model.init_from_data(*args, **kwargs)
+    from .checkpoint import load_weights
+    load_weights(model, file_name)
+    return model
+
+
+def resolve_activation(activation_name):
+    """polus/models.py:53-57 (tfa.activations.mish has no kernel here: the name passes through and the
+    Dense layer rejects what it cannot run)."""
+    return activation_name
+
+
+def from_config(func):
+    """polus/models.py:60-82: the builder is called with nested keyword dicts (at least `model={...}`);
+    it receives them flattened, and the model remembers the nested form + the builder's name as
+    `savable_config`, which is what `.cfg` holds and `load_model` replays.  Flat keyword arguments are
+    accepted too and filed under `model`."""
+    @wraps(func)
+    def function_wrapper(**kwargs):
+        if "model" not in kwargs:
+            kwargs = {"model": {k: v for k, v in kwargs.items() if k != "func_name"}}
+        kwargs = {k: v for k, v in kwargs.items() if k != "func_name"}
+        if "activation" in kwargs["model"]:
+            _activation = kwargs["model"]["activation"]
+            kwargs["model"]["activation"] = resolve_activation(_activation)
+        model = func(**flatten_dict(kwargs))
+        kwargs["func_name"] = func.__name__
+        if "activation" in kwargs["model"]:
+            kwargs["model"]["activation"] = _activation
+        model._name = func.__name__
+        model.savable_config = kwargs
+        return model
+    return function_wrapper
 
 
 class BertConfig:
@@ -265,6 +320,10 @@ class PolusModel:
             self.grad_ready_hook(lo, hi)
 
 
+def _to_numpy(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
 class SavableModel(PolusModel):
     """polus/models.py:107-133: <name><ext>.cfg (JSON config) + weights.  h5py is not in the
     image: weights go to <name><ext>.npz with keys weight0..N in get_weights() order, the
@@ -274,7 +333,18 @@ class SavableModel(PolusModel):
         os.makedirs(base_path, exist_ok=True)
         path = os.path.join(base_path, self.name + extension)
         with open(path + ".cfg", "w") as f:
-            json.dump(json.dumps(self.savable_config, default=str), f)
+            json.dump(complex_json_serializer(self.savable_config), f)
+        if hasattr(self, "_init"):
+            # the reference pickles (args, kwargs) into <name>.init; arrays go to an .npz here (nothing to execute on load)
+            args, kwargs = self._init
+            arrs, spec = {}, {"args": [], "kwargs": {}}
+            for i, a in enumerate(args):
+                arrs[f"arg{i}"] = _to_numpy(a); spec["args"].append(f"arg{i}")
+            for k, a in kwargs.items():
+                if k == "training":
+                    continue
+                arrs[f"kw_{k}"] = _to_numpy(a); spec["kwargs"][k] = f"kw_{k}"
+            np.savez(path + ".init.npz", __spec__=np.asarray(json.dumps(spec)), **arrs)
         w = self.get_weights()
         np.savez(path + ".npz", **{f"weight{i}": a for i, a in enumerate(w)})
         return path
@@ -340,21 +410,34 @@ class SequentialPolusClassifier(Sequential, PolusClassifier):
     pass
 
 
-class BertModel(PolusModel):
-    """Embeddings + encoder (+ optional token-level Dense head).  Input protocol of the HF
-    model the reference calls: input_ids, attention_mask, token_type_ids (int32 [B,S])."""
+class BertModel(SavableModel):
+    """Embeddings + encoder (+ optional HF pooler, + optional token-level Dense head).  Input protocol of
+    the HF model the reference calls: input_ids, attention_mask, token_type_ids (int32 [B,S]).
+
+    `add_pooling_layer=True` adds HF's BertPooler: pooler_output = tanh(W h[:, 0] + b), what the
+    reference reads from an unsplit TFBertModel / TFAutoModel (polus/data.py:526-543); without it
+    pooler_output is the raw [CLS] state, TFBertSplited's convention (polus/models.py:215-216).
+    A SavableModel: `save` writes .cfg (the BertConfig + dtype + head size) and the weights of encoder,
+    pooler and head; `polus_amd.models.load_model` rebuilds it through `bert_model`."""
 
     def __init__(self, cfg, compute_dtype="bf16", num_labels=None, seed=1234, name="bert", with_embeddings=True,
-                 layer_indices=None, arena=None):
+                 layer_indices=None, arena=None, add_pooling_layer=False):
         super().__init__(name)
         self.config = cfg
         self.compute_dtype = COMPUTE_DTYPES[compute_dtype]
+        self.savable_config = {"func_name": "bert_model",
+                               "model": dict(cfg.to_dict(), compute_dtype="bf16" if self.compute_dtype == torch.bfloat16 else "f32",
+                                             num_labels=num_labels, seed=seed, add_pooling_layer=add_pooling_layer)}
         own = arena is None
         self.arena = arena or ParamArena(self.compute_dtype)
         rng = np.random.Generator(np.random.PCG64(seed))
         self.embeddings = BertEmbeddings(cfg, self.arena, rng) if with_embeddings else None
         idx = range(cfg.num_hidden_layers) if layer_indices is None else layer_indices
         self.layer = [BertLayer(cfg, self.arena, i, rng) for i in idx]
+        self.pooler = None
+        if add_pooling_layer:
+            self.pooler = Dense(cfg.hidden_size, activation="tanh", name="pooler")
+            self.pooler.build(self.arena, cfg.hidden_size, "pooler")
         self.head = None
         if num_labels:
             self.head = Dense(num_labels, out_dtype=torch.float32, name="head")
@@ -383,7 +466,15 @@ class BertModel(PolusModel):
             self.head.b.assign(head_b)
 
     def site_seed(self, layer, site, step=None):
-        return dropout_seed(self.dropout_base_seed, self.dropout_step if step is None else step, layer, site)
+        """Seed of one dropout site of this step.  In a data-parallel run every rank draws its own masks
+        (Horovod/TF ranks have independent RNG streams): the rank is folded into the base seed unless
+        `identical_dropout_across_ranks` is set (exact-mask parity tests)."""
+        base = self.dropout_base_seed
+        if not getattr(self, "identical_dropout_across_ranks", False):
+            from . import comm
+            if comm.size() > 1:
+                base = (base ^ (comm.rank() * 0x9E3779B1)) & 0xFFFFFFFF
+        return dropout_seed(base, self.dropout_step if step is None else step, layer, site)
 
     def encode(self, hidden, attention_mask, B, S, training=False):
         cfg = self.config
@@ -421,16 +512,35 @@ class BertModel(PolusModel):
         if self.head is not None:
             return self.head.forward(hidden).view(B, S, -1)
         h3 = hidden.view(B, S, H)
+        if self.pooler is not None:
+            return BaseModelOutputWithPooling(last_hidden_state=h3, pooler_output=self.pooler.forward(h3[:, 0, :], training))
         return BaseModelOutputWithPooling(last_hidden_state=h3, pooler_output=h3[:, 0, :])
 
-    def backward(self, dy, accumulate=False):
-        """dy: gradient wrt the logits [B,S,C] (head) or wrt last_hidden_state [B,S,H]."""
+    def backward(self, dy=None, accumulate=False, dpooled=None):
+        """dy: gradient wrt the logits [B,S,C] (head) or wrt last_hidden_state [B,S,H] (None = zero);
+        dpooled: gradient wrt pooler_output [B,H] (models with the HF pooler, or the raw [CLS] slice)."""
         B, S = self._shape
+        H = self.config.hidden_size
         if self.head is not None:
             dy = self.head.backward(dy.reshape(B * S, -1), accumulate)
             self._notify(self.head.variables())
         else:
-            dy = to_device(dy, self.compute_dtype, self.arena.device).reshape(B * S, -1)
+            if dy is None:
+                dy = torch.zeros((B * S, H), dtype=self.compute_dtype, device=self.arena.device)
+            else:
+                dy = to_device(dy, self.compute_dtype, self.arena.device).reshape(B * S, H)
+            if dpooled is not None:
+                dy = dy.clone()                      # the [CLS] rows are rewritten below: leave the caller's tensor alone
+                d3 = dy.view(B, S, H)
+                dp = to_device(dpooled, self.compute_dtype, self.arena.device).reshape(B, H)
+                if self.pooler is not None:
+                    # d h[:,0] = dpooled-through-the-pooler + dy[:,0]: the residual rides on the dX GEMM's epilogue
+                    dcls = self.pooler.backward(dp, accumulate, dx_resid=d3[:, 0, :])
+                    self._notify(self.pooler.variables())
+                else:
+                    dcls = self.scratch("dcls", (B, H))
+                    ops.gemm(dp, _identity(H, self.compute_dtype, self.arena.device), dcls, resid=d3[:, 0, :])
+                d3[:, 0, :].copy_(dcls)
         if self.overlap_dw and self._side is None:
             self._side = torch.cuda.Stream(device=self.arena.device)
         side = self._side if self.overlap_dw else None
@@ -460,6 +570,28 @@ class BertModel(PolusModel):
         out = torch.empty(l2.shape[0], dtype=torch.int32, device=l2.device)
         ops.argmax(l2, out)
         return out.view(logits.shape[:-1])
+
+
+_EYE = {}
+
+
+def _identity(n, dtype, dev):
+    k = (n, dtype, str(dev))
+    if k not in _EYE:
+        _EYE[k] = torch.eye(n, dtype=dtype, device=dev)
+    return _EYE[k]
+
+
+@from_config
+def bert_model(**kw):
+    """Builder behind BertModel.save / load_model: BertConfig fields + compute_dtype, num_labels, seed,
+    add_pooling_layer."""
+    cfg_keys = ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+                "max_position_embeddings", "type_vocab_size", "layer_norm_eps", "hidden_dropout_prob",
+                "attention_probs_dropout_prob", "_name_or_path")
+    cfg = BertConfig(**{k: kw[k] for k in cfg_keys if k in kw})
+    return BertModel(cfg, compute_dtype=kw.get("compute_dtype", "bf16"), num_labels=kw.get("num_labels"),
+                     seed=kw.get("seed", 1234), add_pooling_layer=kw.get("add_pooling_layer", False))
 
 
 class TFBertSplited(PolusModel):

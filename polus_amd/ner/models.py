@@ -4,7 +4,7 @@ import torch
 
 from .. import ops
 from ..layers import CRF, Dense, Dropout
-from ..models import Sequential, SavableModel
+from ..models import Sequential, SavableModel, from_config, resolve_activation
 
 
 class NERBertModel(SavableModel):
@@ -21,6 +21,7 @@ class SequentialNERBertModel(Sequential, NERBertModel):
     pass
 
 
+@from_config
 def baselineNER_MLP_CRF(sequence_length=256, output_classes=3, hidden_space=128, activation="swish",
                         compute_dtype="f32", input_dim=768, **kwargs):
     crf_layer = CRF(output_classes)
@@ -31,11 +32,10 @@ def baselineNER_MLP_CRF(sequence_length=256, output_classes=3, hidden_space=128,
     ], compute_dtype=compute_dtype, input_dim=input_dim, name=kwargs.get("name", "baselineNER_MLP_CRF"))
     model.loss = crf_layer.loss
     model.loss_sample_weights = crf_layer.loss_sample_weights
-    model.savable_config = dict(func_name="baselineNER_MLP_CRF", sequence_length=sequence_length,
-                                output_classes=output_classes, hidden_space=hidden_space, activation=activation)
     return model
 
 
+@from_config
 def baselineNER_MLP_Dropout_CRF(sequence_length=256, output_classes=3, hidden_space=128, droupout_p=0.0,
                                 activation="swish", compute_dtype="f32", input_dim=768, **kwargs):
     crf_layer = CRF(output_classes)

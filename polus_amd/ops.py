@@ -258,6 +258,15 @@ def argmax(x, out, rows=None, C=None):
     check(lib.polus_argmax(ptr(x), x.stride(0), ptr(out), rows, C, _st()), "polus_argmax")
 
 
+def confusion_matrix(row_idx, col_idx, cm):
+    """cm[row_idx[i], col_idx[i]] += 1 (int32 [C, C] on the device)."""
+    _req_cuda(row_idx, col_idx, cm)
+    assert row_idx.dtype == torch.int32 and col_idx.dtype == torch.int32 and cm.dtype == torch.int32
+    assert row_idx.numel() == col_idx.numel() and row_idx.is_contiguous() and col_idx.is_contiguous() and cm.is_contiguous()
+    check(_lib.load().polus_confusion_matrix(ptr(row_idx), ptr(col_idx), row_idx.numel(), cm.shape[0], ptr(cm), _st()),
+          "polus_confusion_matrix")
+
+
 def adam_step(p, g, m, v, shadow, seg, n_seg, lr, lr_t, beta1, beta2, eps, weight_decay, grad_scale=1.0,
               clip_scale=None):
     lib = _lib.load()
@@ -275,8 +284,17 @@ def sqnorm(g, out):
     check(lib.polus_sqnorm(ptr(g), g.numel(), ptr(out), ptr(ws), nb, _st()), "polus_sqnorm")
 
 
+def sqnorm_segments(g, seg, n_seg, out):
+    """sum of g^2 over the windows of the Adam segment table `seg` (int64 [n_seg, 3]) -> out[0]."""
+    lib = _lib.load()
+    _req_cuda(g, seg, out)
+    ws = workspace(g.device).get(4096)
+    check(lib.polus_sqnorm_segments(ptr(g), ptr(seg), int(n_seg), ptr(out), ptr(ws), 4096, _st()), "polus_sqnorm_segments")
+
+
 def clip_scale(sq, grad_scale, clip_norm, out):
-    check(_lib.load().polus_clip_scale(ptr(sq), float(grad_scale), float(clip_norm), ptr(out), _st()), "polus_clip_scale")
+    """out = clip_norm / max(sqrt(sum(sq)) * |grad_scale|, clip_norm); sq holds one partial sum per arena."""
+    check(_lib.load().polus_clip_scale(ptr(sq), sq.numel(), float(grad_scale), float(clip_norm), ptr(out), _st()), "polus_clip_scale")
 
 
 def cast(src, dst):

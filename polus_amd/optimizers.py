@@ -133,15 +133,20 @@ class Adam:
         arenas = {}
         for v in variables:
             arenas.setdefault(id(v.arena), (v.arena, []))[1].append(v)
+        clip = None
+        if self.global_clipnorm:
+            # tf.clip_by_global_norm: ONE norm over the gradients being applied -- every arena, and only the
+            # windows of the variables in this call (frozen or stale gradient windows do not count)
+            dev0 = next(iter(arenas.values()))[0].device
+            sq = torch.empty(len(arenas), dtype=torch.float32, device=dev0)
+            clip = torch.empty(1, dtype=torch.float32, device=dev0)
+            for k, (arena, vs) in enumerate(arenas.values()):
+                seg, n_seg = self._table(arena, vs)
+                ops.sqnorm_segments(arena.grads, seg, n_seg, sq[k:k + 1])
+            ops.clip_scale(sq, self.grad_scale, self.global_clipnorm, clip)
         for arena, vs in arenas.values():
             m, v = self._slots(arena)
             seg, n_seg = self._table(arena, vs)
-            clip = None
-            if self.global_clipnorm:
-                sq = torch.empty(1, dtype=torch.float32, device=arena.device)
-                clip = torch.empty(1, dtype=torch.float32, device=arena.device)
-                ops.sqnorm(arena.grads, sq)
-                ops.clip_scale(sq, self.grad_scale, self.global_clipnorm, clip)
             ops.adam_step(arena.params, arena.grads, m, v, arena.shadow, seg, n_seg, lr, lr_t,
                           self.beta_1, self.beta_2, self.epsilon, self.weight_decay_rate,
                           grad_scale=self.grad_scale, clip_scale=clip)

@@ -177,3 +177,118 @@ def test_metrics_and_shard_rule():
     assert abs(oo.macro_f1(cm) - (1 + 2 / 3 + 0.8) / 3) < 1e-12
     assert oo.macro_f1(np.zeros((3, 3), np.int32)) == 0.0      # divide_no_nan
     assert oo.shard_indices(10, 4, 1) == [1, 5, 9]              # polus/data.py:94-96
+
+
+def test_adam_pinned_to_torch_optim():
+    """oracle.optim.Adam (the Keras form: p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps), eps OUTSIDE the
+    bias-corrected root) against torch.optim.Adam / AdamW, an independent implementation.  torch divides
+    by sqrt(v/(1-b2^t)) + eps_t; the two are the same update when eps_t = eps/sqrt(1-b2^t):
+        lr/(1-b1^t) * m / (sqrt(v)/sqrt(c2) + eps_t) = lr*sqrt(c2)/(1-b1^t) * m / (sqrt(v) + eps_t*sqrt(c2)).
+    So (a) with that per-step eps_t the trajectories agree to rounding -- this pins the moment updates,
+    both bias corrections, the decoupled decay (AdamW: p *= 1 - lr*wd with the UNcorrected lr, as HF
+    AdamWeightDecay) and the epsilon placement; (b) with the same constant eps on both sides they differ by
+    at most |dp| * eps*(1/sqrt(c2)-1)/sqrt(v), checked as a bound."""
+    import torch
+    r = np.random.Generator(np.random.PCG64(5))
+    shapes = {"w": (7, 5), "ln.g": (5,), "b": (7,)}
+    for wd in (0.0, 0.01):
+        p = {k: r.standard_normal(s) for k, s in shapes.items()}
+        tp = {k: torch.tensor(v.copy(), dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+        nod = ["ln.g", "b"]
+        opt = oo.Adam(lr=3e-3, eps=1e-7, weight_decay=wd, no_decay=nod)
+        groups = [{"params": [tp["w"]], "weight_decay": wd}, {"params": [tp[k] for k in nod], "weight_decay": 0.0}]
+        topt = torch.optim.AdamW(groups, lr=3e-3, betas=(0.9, 0.999), eps=1e-7)
+        for t in range(1, 13):
+            g = {k: r.standard_normal(s) * 10.0 ** r.integers(-6, 1) for k, s in shapes.items()}
+            for k in tp:
+                tp[k].grad = torch.tensor(g[k].copy(), dtype=torch.float64)
+            for grp in topt.param_groups:
+                grp["eps"] = 1e-7 / np.sqrt(1.0 - 0.999 ** t)
+            opt.step(p, g)
+            topt.step()
+            for k in p:
+                assert np.allclose(p[k], tp[k].detach().numpy(), rtol=1e-12, atol=1e-15), (wd, t, k)
+    # (b) same constant eps on both sides: bounded difference after one step from identical state
+    p = {"w": r.standard_normal((50,))}
+    g = {"w": r.standard_normal((50,)) * 1e-3}
+    tw = torch.tensor(p["w"].copy(), dtype=torch.float64, requires_grad=True)
+    tw.grad = torch.tensor(g["w"].copy(), dtype=torch.float64)
+    oo.Adam(lr=1e-3, eps=1e-7).step(p, g)
+    torch.optim.Adam([tw], lr=1e-3, eps=1e-7).step()
+    c2 = 1.0 - 0.999
+    step = 1e-3                                   # |dp| <= lr at t = 1
+    bound = step * 1e-7 * (1.0 / np.sqrt(c2) - 1.0) / np.sqrt(0.001 * g["w"] ** 2)
+    assert np.all(np.abs(p["w"] - tw.detach().numpy()) <= bound * 1.0001 + 1e-18)
+
+
+def test_schedule_table_against_reference_closed_form():
+    """polus/schedulers.py:10-23 = WarmUp(power 1) over PolynomialDecay(power 1, end 1e-7), written out
+    independently: every integer step of a run and past its end."""
+    for N, pct, lr in ((100, 0.1, 1e-3), (1000, 0.1, 5e-5), (37, 0.25, 2e-4)):
+        W = int(N * pct)
+        D = N - W
+        for t in range(0, 2 * N + 3):
+            if t < W:
+                ref = lr * (t / W) ** 1.0
+            else:
+                s = min(t - W, D)
+                ref = (lr - 1e-7) * (1.0 - s / D) ** 1.0 + 1e-7
+            assert abs(oo.warmup_linear_lr(t, N, lr, pct) - ref) <= 1e-18 + 1e-15 * ref, (N, t)
+
+
+def test_torch_cpu_port_matches_numpy_oracle():
+    """oracle/bert_torch.py (the cpu_baseline leg of bench.py) computes the same step as the NumPy
+    oracle: loss, logits, every gradient (autograd vs the explicit backward) and three AdamW steps."""
+    import torch
+    from oracle import bert_torch as bt
+    cfg = ob.BertConfig(97, 128, 2, 2, 256, 64, 2)
+    params, hw, hb = ob.golden_setup(cfg, 4)
+    r = np.random.Generator(np.random.PCG64(9))
+    ids = r.integers(1, 97, size=(3, 24)).astype(np.int32)
+    mask = (np.arange(24)[None] < np.array([24, 9, 17])[:, None]).astype(np.int32)
+    tt = (r.integers(0, 2, size=(3, 24)) * mask).astype(np.int32)
+    labels = (r.integers(0, 4, size=(3, 24)) * mask).astype(np.int32)
+    allp = dict(params); allp["head.w"] = hw; allp["head.b"] = hb
+    tp = bt.to_torch(allp, torch.float64)
+    loss, logits, cache = ob.token_classifier_fwd(allp, cfg, allp["head.w"], allp["head.b"], ids, mask, labels, tt)
+    tl, tlogits = bt.token_classifier_loss(tp, cfg, ids, mask, labels, tt)
+    assert abs(float(tl.detach()) - loss) < 1e-12
+    assert np.abs(tlogits.detach().numpy() - logits).max() < 1e-11
+    tl.backward()
+    grads = ob.token_classifier_bwd(allp, cfg, allp["head.w"], cache)
+    for k, g in grads.items():
+        assert np.abs(tp[k].grad.numpy() - g).max() <= 1e-10 * max(1.0, np.abs(g).max()), k
+    for k in tp:
+        tp[k].grad = None
+    nod = [k for k in allp if oo.is_no_decay(k)]
+    o_np = oo.Adam(lr=lambda t: oo.warmup_linear_lr(t, 10, 1e-3), weight_decay=0.01, no_decay=nod)
+    o_t = bt.Adam(lr=lambda t: oo.warmup_linear_lr(t, 10, 1e-3), weight_decay=0.01, no_decay=nod)
+    for s in range(3):
+        l_np, _, cache = ob.token_classifier_fwd(allp, cfg, allp["head.w"], allp["head.b"], ids, mask, labels, tt)
+        o_np.step(allp, ob.token_classifier_bwd(allp, cfg, allp["head.w"], cache))
+        l_t = bt.train_step(tp, cfg, o_t, ids, mask, labels, tt)
+        assert abs(l_np - l_t) < 1e-10, (s, l_np, l_t)
+    for k in allp:
+        assert np.abs(tp[k].detach().numpy() - allp[k]).max() < 1e-10, k
+
+
+def test_pooler_matches_hf_twin():
+    """oracle.bert.pooler_fwd / pooler_bwd against transformers' BertPooler (float64, autograd)."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    from transformers.models.bert.modeling_bert import BertPooler
+    hc = tr.BertConfig(hidden_size=64, num_attention_heads=1, num_hidden_layers=1, intermediate_size=64, vocab_size=10)
+    torch.manual_seed(1)
+    pool = BertPooler(hc).double()
+    r = np.random.Generator(np.random.PCG64(4))
+    h = r.standard_normal((3, 7, 64))
+    w, b = pool.dense.weight.detach().numpy(), pool.dense.bias.detach().numpy()
+    ht = torch.tensor(h, requires_grad=True)
+    out = pool(ht)
+    pooled, cache = ob.pooler_fwd(h, w, b)
+    assert np.abs(pooled - out.detach().numpy()).max() < 1e-13
+    dp = r.standard_normal((3, 64))
+    out.backward(torch.tensor(dp))
+    dlast, dw, db = ob.pooler_bwd(dp, w, cache, 7)
+    assert np.abs(dlast - ht.grad.numpy()).max() < 1e-12
+    assert np.abs(dw - pool.dense.weight.grad.numpy()).max() < 1e-12 and np.abs(db - pool.dense.bias.grad.numpy()).max() < 1e-12
