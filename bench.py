@@ -54,7 +54,20 @@ def synth_batch(B, S, seed, vocab=VOCAB, C=N_LABELS):
     return ids, mask, np.zeros_like(ids), labels
 
 
-def cpu_baseline(S, L, H, A, I, B=8, warm=3, timed=5):
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    shows all 256 hardware threads but schedules a one-GPU job on its share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(S, L, H, A, I, B=8, warm=3, timed=5, budget_s=90.0):
     """The same training step (forward, mean CE, backward, AdamW) as a torch-CPU eager fp32 restatement
     (oracle/bert_torch.py, pinned to the NumPy oracle by tests/test_oracle_golden.py) on this box's host
     cores: SURVEY.md §8(d) -- B=8, 3 warm-up + 5 timed steps, all cores."""
@@ -62,7 +75,8 @@ def cpu_baseline(S, L, H, A, I, B=8, warm=3, timed=5):
     from oracle import bert as ob
     from oracle import bert_torch as bt
     from oracle import optim as oo
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = host_cores()
+    torch.set_num_threads(cores)
     cfg = ob.BertConfig(VOCAB, H, L, A, I, 512, 2)
     params = ob.init_params(cfg, seed=1234, dtype=np.float32)
     rng = np.random.Generator(np.random.PCG64(7))
@@ -75,16 +89,25 @@ def cpu_baseline(S, L, H, A, I, B=8, warm=3, timed=5):
         ids, mask, tt, labels = synth_batch(B, S, seed)
         return bt.train_step(p, cfg, opt, ids, mask, labels, tt)
 
+    tw = time.perf_counter()
+    done_warm = 0
     for k in range(warm):
         step(k)
+        done_warm += 1
+        if time.perf_counter() - tw > budget_s * 0.4:      # a slow host: keep the whole leg bounded
+            break
     t0 = time.perf_counter()
+    done = 0
     for k in range(timed):
         step(warm + k)
+        done += 1
+        if done >= 2 and time.perf_counter() - t0 > budget_s * 0.6:
+            break
     dt = time.perf_counter() - t0
-    return {"value": round(B * timed / dt, 3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(B * done / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"torch-CPU eager fp32 restatement of the step (oracle/bert_torch.py), B={B} S={S} "
-                      f"BERT-base L={L}, {timed} timed steps after {warm} warm-up ({dt:.1f} s), "
-                      f"torch threads = {torch.get_num_threads()}"}
+                      f"BERT-base L={L}, {done} timed steps after {done_warm} warm-up ({dt:.1f} s), "
+                      f"torch threads = {torch.get_num_threads()} (host shows {os.cpu_count()} hardware threads)"}
 
 
 def build_trainer(args, dtype, dropout, total_steps):
