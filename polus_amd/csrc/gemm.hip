@@ -546,11 +546,21 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
 // matrix (each split is an f32 slab written and read back).  All problems share T and accumulate.
 // split_k > 0: that many splits for every problem; split_k <= 0: chosen per problem so that the
 // launch is one full round of the 2 x #CU workgroup slots.
-static void grouped_splits(int n, const polus_dw_problem* pr, int T, int split_k, int* splits) {
+// Which kernel runs the grouped dW launch: the ping-pong 256 x 256 kernel (gemm_ppks.hip, one workgroup per CU)
+// when every problem is at least one tile in both directions and T is whole K-tiles, else the ring kernel
+// (256 x 128 tiles, two workgroups per CU).
+static bool grouped_use_pp(int n, const polus_dw_problem* pr, int T) {
+    if (polus_cfg().gemm_pp < 0 || T % 64 != 0) return false;
+    for (int k = 0; k < n; ++k)
+        if (pr[k].n_out < 256 || pr[k].n_in < 256) return false;
+    return true;
+}
+
+static void grouped_splits(int n, const polus_dw_problem* pr, int T, int split_k, int* splits, bool pp) {
     const int nkt = (T + 63) / 64;
     int tiles[POLUS_MAX_GROUP], total = 0;
     for (int k = 0; k < n; ++k) {
-        tiles[k] = ((pr[k].n_out + 255) / 256) * ((pr[k].n_in + 127) / 128);
+        tiles[k] = pp ? polus_ppks_tiles(pr[k].n_out, pr[k].n_in) : ((pr[k].n_out + 255) / 256) * ((pr[k].n_in + 127) / 128);
         total += tiles[k];
     }
     if (split_k > 0) {
@@ -559,8 +569,9 @@ static void grouped_splits(int n, const polus_dw_problem* pr, int T, int split_k
     }
     // Workgroups go to the 8 XCDs round-robin and each tile list is padded to a multiple of 8, so
     // XCD 0 receives ceil(tiles/8) workgroups of every (problem, split).  All workgroups run for
-    // about the same (long) time: one more than 2 x CUs-per-XCD on any XCD doubles the kernel.
-    const int slots_xcd = 2 * polus_num_cus() / 8;
+    // about the same (long) time: one more than the resident workgroups per XCD (2 per CU for the ring
+    // kernel, 1 for the ping-pong kernel) on any XCD doubles the kernel.
+    const int slots_xcd = (pp ? 1 : 2) * polus_num_cus() / 8;
     int per_xcd[POLUS_MAX_GROUP], total_xcd = 0;
     for (int k = 0; k < n; ++k) { per_xcd[k] = (tiles[k] + 7) / 8; total_xcd += per_xcd[k]; }
     int base = slots_xcd / (total_xcd > 0 ? total_xcd : 1);
@@ -594,7 +605,7 @@ static size_t grouped_need(int n, const polus_dw_problem* pr, const int* splits,
 extern "C" size_t polus_dense_bwd_params_grouped_workspace_bytes(int n, const polus_dw_problem* problems, int T, int split_k) {
     if (n < 1 || n > POLUS_MAX_GROUP || !problems || T < 1) return 0;
     int splits[POLUS_MAX_GROUP];
-    grouped_splits(n, problems, T, split_k, splits);
+    grouped_splits(n, problems, T, split_k, splits, grouped_use_pp(n, problems, T));
     size_t so[POLUS_MAX_GROUP], co[POLUS_MAX_GROUP];
     size_t grouped = grouped_need(n, problems, splits, so, co);
     size_t single = 0;   // fallback path runs them one by one
@@ -616,8 +627,9 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         ring = ring && polus_aligned16(q.dY) && polus_aligned16(q.X) && ((q.lddy * es) % 16 == 0) && ((q.ldx * es) % 16 == 0) &&
                (q.n_out % 8 == 0) && (q.n_in % 8 == 0) && q.n_out >= 256 && q.n_in >= 128;
     }
+    const bool pp = ring && grouped_use_pp(n, problems, T);
     int splits[POLUS_MAX_GROUP];
-    grouped_splits(n, problems, T, split_k, splits);
+    grouped_splits(n, problems, T, split_k, splits, grouped_use_pp(n, problems, T));
     size_t need = polus_dense_bwd_params_grouped_workspace_bytes(n, problems, T, split_k);
     if (!workspace || workspace_bytes < need) { polus_set_error("polus_dense_bwd_params_grouped: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
     if (!ring) {
@@ -666,8 +678,23 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
             a.epi_vec = polus_aligned16(q.dW) && (q.lddw % 4 == 0); a.epi_vec16 = a.epi_vec;
         }
     }
-    int rc = polus_launch_gemm_ring_grouped_dw(ga, n, eff, st);
+    int rc = pp ? polus_launch_gemm_ppks_grouped_dw(ga, n, eff, st) : polus_launch_gemm_ring_grouped_dw(ga, n, eff, st);
     if (rc != POLUS_OK) return rc;
+    if (polus_cfg().dw_fused_reduce) {
+        // every slab reduction and every bias-gradient finalisation of the group in ONE launch
+        const float* slabs[POLUS_MAX_GROUP]; const float* cs[POLUS_MAX_GROUP];
+        float* dWs[POLUS_MAX_GROUP]; float* dbs[POLUS_MAX_GROUP];
+        long ldw[POLUS_MAX_GROUP]; int no[POLUS_MAX_GROUP], ni[POLUS_MAX_GROUP];
+        bool fusable = true;
+        for (int k = 0; k < n; ++k) {
+            const polus_dw_problem& q = problems[k];
+            slabs[k] = eff[k] > 1 ? reinterpret_cast<const float*>(ws + so[k]) : nullptr;
+            cs[k] = q.db ? reinterpret_cast<const float*>(ws + co[k]) : nullptr;
+            dWs[k] = q.dW; dbs[k] = q.db; ldw[k] = q.lddw; no[k] = q.n_out; ni[k] = q.n_in;
+            fusable = fusable && (q.n_in % 4 == 0) && (q.lddw % 4 == 0) && polus_aligned16(q.dW);
+        }
+        if (fusable) return polus_launch_dw_group_reduce(n, slabs, cs, dWs, dbs, ldw, no, ni, eff, accumulate ? 1 : 0, st);
+    }
     for (int k = 0; k < n; ++k) {
         const polus_dw_problem& q = problems[k];
         if (eff[k] > 1) {

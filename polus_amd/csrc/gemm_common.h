@@ -378,3 +378,10 @@ int polus_launch_gemm_p(const pgemm::GemmArgs& a, int mode, int drop, int tn, in
 // gemm_pp.hip: 256 x tn tile (tn = 256 or 192), 8 waves in two half-phase-staggered groups, one workgroup per
 // CU, both operands K-contiguous, K % 64 == 0, bf16 C, mode from polus_gemm_p_mode.
 int polus_launch_gemm_pp(const pgemm::GemmArgs& a, int mode, int drop, int tn, hipStream_t st);
+// gemm_ppks.hip: the grouped dW launch on 256 x 256 tiles (both operands K-strided, f32 C / slabs, K % 64 == 0),
+// and the one-launch reduction of a group's slabs and bias-gradient partials.
+int polus_ppks_tiles(int n_out, int n_in);
+int polus_launch_gemm_ppks_grouped_dw(const pgemm::GemmArgs* probs, int n, const int* splits, hipStream_t st);
+int polus_launch_dw_group_reduce(int n, const float* const* slabs, const float* const* cs, float* const* dW, float* const* db,
+                                 const long* lddw, const int* n_out, const int* n_in, const int* splits, int accumulate,
+                                 hipStream_t st);

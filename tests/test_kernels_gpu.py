@@ -692,6 +692,21 @@ def test_dense_bwd_params_grouped(ops, T, split_k):
                 dw1, db1 = torch.empty_like(dw), torch.empty_like(db)
                 ops.dense_bwd_params(dy, x, dw1, db1, split_k=split_k)
                 assert torch.equal(dw, dw1) and torch.equal(db, db1), "grouped launch differs from the single-matrix one"
+    # the ping-pong 256 x 256 kernel (default where T is whole K-tiles) and the ring kernel agree bit for bit
+    # (same k order inside a slice, same slice-ordered reduction), fused or per-matrix reduce launches alike
+    for env, val in (("POLUS_GEMM_PP", -1), ("POLUS_DW_FUSED_REDUCE", 0)):
+        ops.set_env(env, val)
+        try:
+            alt = [(torch.full_like(p[2], float("nan")), None if p[3] is None else torch.full_like(p[3], float("nan"))) for p in probs]
+            ops.dense_bwd_params_grouped([(p[0], p[1], a[0], a[1]) for p, a in zip(probs, alt)], False, split_k)
+        finally:
+            ops.set_env(env)
+        if env == "POLUS_DW_FUSED_REDUCE" or split_k > 0:      # with library-chosen splits the two kernels cut K differently
+            for (dy, x, dw, db), (aw, ab) in zip(probs, alt):
+                assert torch.equal(dw, aw) and (db is None or torch.equal(db, ab)), env
+        else:
+            for (dy, x, dw, db), (aw, ab) in zip(probs, alt):
+                assert_close(host(aw), host(dw), 1e-5, "ring vs ping-pong dW")
     first = [(p[2].clone(), None if p[3] is None else p[3].clone()) for p in probs]
     ops.dense_bwd_params_grouped(probs, True, split_k)
     for (dy, x, dw, db), (w0, b0) in zip(probs, first):
