@@ -249,6 +249,29 @@ int polus_act_bwd(int dtype, const void* dy, const void* u, void* du, int64_t n,
 /* y = a*x elementwise, f32 (gradient averaging when the comm backend lacks AVG) */
 int polus_scale(float* x, float a, int64_t n, void* stream);
 
+/* ---- data-parallel collectives over RCCL / xGMI: the device side of the six Horovod touch points of the
+ * reference -- hvd.init (polus/__init__.py:109-122), hvd.DistributedGradientTape's gradient averaging
+ * (polus/training.py:182-185) and hvd.broadcast_variables (polus/training.py:210-211).
+ * One communicator per process (one process per GPU).  Rank 0 draws a 128-byte id with polus_comm_unique_id and
+ * hands it to the other ranks over any host channel (the Python side uses the torchrun TCP store); every rank
+ * then calls polus_comm_init(rank, world, id).  Collectives are queued on `stream` and return immediately; buffers
+ * are device pointers; `dtype` is POLUS_F32 or POLUS_BF16 (bf16 = half the bytes on the links, sums rounded to bf16).
+ *   allreduce_sum      buf[count] := sum over ranks (in place); the 1/world factor is folded into polus_adam_step
+ *   reduce_scatter_sum recv[recv_count] := rank's slice of the sum of send[world * recv_count]
+ *   all_gather         recv[world * send_count] := concatenation of every rank's send[send_count]
+ *   broadcast          buf[bytes] := root's buf
+ * group_start / group_end bracket several collectives into one RCCL launch. */
+#define POLUS_COMM_ID_BYTES 128
+int polus_comm_unique_id(void* out_id128);
+int polus_comm_init(void** comm, int rank, int world, const void* unique_id128);
+int polus_comm_destroy(void* comm);
+int polus_comm_broadcast(void* comm, void* buf, size_t bytes, int root, void* stream);
+int polus_comm_allreduce_sum(void* comm, void* buf, size_t count, int dtype, void* stream);
+int polus_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, size_t recv_count, int dtype, void* stream);
+int polus_comm_all_gather(void* comm, const void* send, void* recv, size_t send_count, int dtype, void* stream);
+int polus_comm_group_start(void);
+int polus_comm_group_end(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,15 @@ SIGNATURES = {
     "polus_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "polus_dense_bwd_params_grouped_workspace_bytes": (_sz, [_i, _vp, _i, _i]),
     "polus_dense_bwd_params_grouped": (_i, [_i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_comm_unique_id": (_i, [_vp]),
+    "polus_comm_init": (_i, [_c.POINTER(_vp), _i, _i, _vp]),
+    "polus_comm_destroy": (_i, [_vp]),
+    "polus_comm_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "polus_comm_allreduce_sum": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "polus_comm_reduce_scatter_sum": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "polus_comm_all_gather": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "polus_comm_group_start": (_i, []),
+    "polus_comm_group_end": (_i, []),
 }
 
 

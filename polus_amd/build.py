@@ -65,7 +65,7 @@ def build(force=False, verbose=True):
     rebuilt = any(ch for _, ch in results)
     out = lib_path()
     if rebuilt or force or not os.path.exists(out):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

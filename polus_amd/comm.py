@@ -1,24 +1,40 @@
-"""Data-parallel communication for the Polus step: RCCL over xGMI through torch.distributed.
+"""Data-parallel communication for the Polus step: RCCL over xGMI, one process per GPU.
 
 Replaces the six Horovod touch points of the reference (polus/mock/horovod.py:5-24 lists the
 surface; call sites polus/__init__.py:109-122, polus/training.py:182,210-211,
-polus/callbacks.py:249): one process per GPU launched by torchrun, backend "nccl" (= RCCL on
-ROCm) when a GPU is visible, "gloo" for the CPU multi-process tests.
+polus/callbacks.py:249).  Two planes:
 
-Horovod's DistributedGradientTape averages every gradient tensor with one all-reduce per
-tensor fused by a background thread.  Here the gradients already live in one flat f32 arena
-laid out in forward order, so the reducer cuts it into contiguous buckets from the END (the
-order backward produces them) and issues one all-reduce (SUM) per bucket as soon as the
-model reports the bucket's lowest tensor final; RCCL runs it on the process group's own
-stream beside the remaining backward kernels.  The 1/world factor is folded into the
-optimizer's gradient scale instead of a separate pass.
-"""
+* control plane (host objects, barriers, the 128-byte RCCL id): a `gloo` process group over the
+  torchrun rendezvous -- plumbing;
+* data plane (gradients, parameters): the `polus_comm_*` entry points of libpolus_hip.so over RCCL
+  (include/polus_hip.h), queued on a side HIP stream and fenced against the compute stream with events.
+  `POLUS_DIST_BACKEND=nccl` swaps in torch.distributed's own RCCL binding, `gloo` the CPU transport (the
+  multi-process tests, and several ranks sharing one GPU -- RCCL refuses duplicate devices).  If the native
+  communicator cannot be brought up on some rank, every rank falls back to the torch binding together.
+
+Horovod's DistributedGradientTape averages every gradient tensor with one all-reduce per tensor fused
+by a background thread.  Here the gradients already live in one flat f32 arena laid out in forward
+order, so `GradBucketReducer` cuts it into contiguous buckets from the END (the order backward produces
+them) and starts a bucket's collective as soon as the model reports everything above its lower edge
+final.  Two exchange schemes:
+
+* `allreduce`: all-reduce (SUM) per bucket; every rank then runs the full AdamW update;
+* `rs` (default on the data plane above): reduce-scatter per bucket -- rank r ends up with the sum of
+  slice r of every bucket -- each rank runs AdamW on its slices only (1/N of the optimizer's HBM
+  traffic), then one all-gather per bucket returns the updated f32 parameters to everyone.  On the xGMI
+  mesh a reduce-scatter / all-gather pair moves bytes/N per link and phase over all links at once
+  (SURVEY.md §5), where a ring all-reduce pushes 2 (N-1)/N of the bytes through one link per direction.
+  Optional bf16 transport of the gradients (`POLUS_DP_BF16=1`) halves the reduce-scatter bytes.
+
+The 1/world (and 1/accumulation) factor is folded into the optimizer's gradient scale instead of a
+separate pass."""
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
-_STATE = {"initialized": False, "world": 1, "rank": 0, "local_rank": 0, "backend": None}
+_STATE = {"initialized": False, "world": 1, "rank": 0, "local_rank": 0, "backend": None, "plane": None}
 
 
 def _env_int(name, default):
@@ -26,6 +42,166 @@ def _env_int(name, default):
         return int(os.environ.get(name, default))
     except ValueError:
         return default
+
+
+# ------------------------------------------------------------------------------------ data planes
+class _Done:
+    """A collective that is already ordered with respect to its consumer."""
+
+    def wait(self):
+        pass
+
+
+class _TorchPlane:
+    """torch.distributed collectives on a process group (gloo on CPU, nccl = RCCL on GPUs)."""
+    name = "torch"
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_reduce_sum(self, t):
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def reduce_scatter_sum(self, send, recv):
+        return dist.reduce_scatter_tensor(recv, send, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def all_gather(self, send, recv):
+        return dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+
+    def broadcast(self, t, root):
+        dist.broadcast(t, src=root, group=self.group)
+
+    def close(self):
+        pass
+
+
+class _GlooPlane(_TorchPlane):
+    """gloo has no reduce_scatter_tensor / all_gather_into_tensor on every build: spell them with all_reduce /
+    all_gather (tests only; the byte counts of the real plane do not matter here)."""
+    name = "gloo"
+
+    def reduce_scatter_sum(self, send, recv):
+        tmp = send.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+        n = recv.numel()
+        recv.copy_(tmp[rank() * n:(rank() + 1) * n])
+        return _Done()
+
+    def all_gather(self, send, recv):
+        n = send.numel()
+        parts = [torch.empty_like(send) for _ in range(size())]
+        dist.all_gather(parts, send.contiguous(), group=self.group)
+        for r, p in enumerate(parts):
+            recv[r * n:(r + 1) * n].copy_(p)
+        return _Done()
+
+
+class _StreamHandle:
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class _NativePlane:
+    """polus_comm_* (RCCL through the C ABI) on a side HIP stream.  Every call first makes that stream wait
+    for what the compute stream has queued so far; the handle's wait() makes the compute stream wait for
+    the collective."""
+    name = "native"
+
+    def __init__(self, world, rk):
+        from . import _lib
+        # the RCCL copy that shares torch's HIP runtime (same SONAME as /opt/rocm's)
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+        self.lib = _lib.load()
+        self.check = _lib.check
+        uid = (ctypes.c_ubyte * 128)()
+        if rk == 0:
+            self.check(self.lib.polus_comm_unique_id(uid), "polus_comm_unique_id")
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)            # control plane (gloo)
+        uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        self.comm = ctypes.c_void_p()
+        self.check(self.lib.polus_comm_init(ctypes.byref(self.comm), rk, world, uid), "polus_comm_init")
+        self.stream = torch.cuda.Stream()
+        self.world, self.rank = world, rk
+
+    def _enter(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.stream.wait_event(ev)
+
+    def _leave(self):
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return _StreamHandle(ev)
+
+    @staticmethod
+    def _dt(t):
+        from ._lib import dtype_code
+        return dtype_code(t.dtype)
+
+    def all_reduce_sum(self, t):
+        self._enter()
+        self.check(self.lib.polus_comm_allreduce_sum(self.comm, t.data_ptr(), t.numel(), self._dt(t), self.stream.cuda_stream),
+                   "polus_comm_allreduce_sum")
+        return self._leave()
+
+    def reduce_scatter_sum(self, send, recv):
+        assert send.numel() == recv.numel() * self.world and send.dtype == recv.dtype
+        self._enter()
+        self.check(self.lib.polus_comm_reduce_scatter_sum(self.comm, send.data_ptr(), recv.data_ptr(), recv.numel(),
+                                                          self._dt(send), self.stream.cuda_stream), "polus_comm_reduce_scatter_sum")
+        return self._leave()
+
+    def all_gather(self, send, recv):
+        assert recv.numel() == send.numel() * self.world and send.dtype == recv.dtype
+        self._enter()
+        self.check(self.lib.polus_comm_all_gather(self.comm, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                                  self._dt(send), self.stream.cuda_stream), "polus_comm_all_gather")
+        return self._leave()
+
+    def broadcast(self, t, root):
+        self._enter()
+        self.check(self.lib.polus_comm_broadcast(self.comm, t.data_ptr(), t.numel() * t.element_size(), int(root),
+                                                 self.stream.cuda_stream), "polus_comm_broadcast")
+        self._leave().wait()
+
+    def close(self):
+        if self.comm:
+            torch.cuda.synchronize()
+            self.lib.polus_comm_destroy(self.comm)
+            self.comm = ctypes.c_void_p()
+
+
+def _bring_up_native(world, rk):
+    """Native communicator + a one-element all-reduce as a self-test; every rank learns whether ALL succeeded."""
+    plane, err = None, None
+    try:
+        plane = _NativePlane(world, rk)
+        probe = torch.ones(4, dtype=torch.float32, device="cuda")
+        plane.all_reduce_sum(probe).wait()
+        torch.cuda.synchronize()
+        if not torch.equal(probe.cpu(), torch.full((4,), float(world))):
+            raise RuntimeError(f"self-test all-reduce returned {probe.tolist()} for world size {world}")
+    except Exception as e:      # noqa: BLE001 -- any failure means: use the other binding, together
+        err = e
+    oks = [None] * world
+    dist.all_gather_object(oks, err is None)
+    if all(oks):
+        return plane
+    if plane is not None:
+        try:
+            plane.close()
+        except Exception:       # noqa: BLE001
+            pass
+    from .context import logger
+    logger.warning(f"native RCCL plane unavailable on rank(s) {[r for r, ok in enumerate(oks) if not ok]} "
+                   f"({err}); falling back to torch.distributed's RCCL binding")
+    return None
 
 
 def init():
@@ -37,27 +213,41 @@ def init():
     _STATE["initialized"] = True
     if world <= 1:
         return "mock"
-    rank, local_rank = _env_int("RANK", 0), _env_int("LOCAL_RANK", 0)
+    rk, local_rank = _env_int("RANK", 0), _env_int("LOCAL_RANK", 0)
     use_gpu = torch.cuda.is_available()
-    # POLUS_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices)
-    backend = os.environ.get("POLUS_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+    backend = os.environ.get("POLUS_DIST_BACKEND") or ("native" if use_gpu else "gloo")
     if use_gpu:
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        kw = {}
-        if use_gpu and backend == "nccl":
-            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-    _STATE.update(world=dist.get_world_size(), rank=dist.get_rank(), local_rank=local_rank, backend=backend)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rk, world_size=world,
+                                    device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend="gloo", rank=rk, world_size=world)
+    _STATE.update(world=dist.get_world_size(), rank=dist.get_rank(), local_rank=local_rank)
+    plane = None
+    if backend == "native":
+        plane = _bring_up_native(world, rk)
+        if plane is None:
+            backend = "nccl"
+            plane = _TorchPlane(dist.new_group(backend="nccl"))
+    elif backend == "nccl":
+        plane = _TorchPlane(None)
+    else:
+        plane = _GlooPlane(None)
+    _STATE.update(backend=backend, plane=plane)
     return backend
 
 
 def shutdown():
+    plane = _STATE.get("plane")
+    if plane is not None:
+        plane.close()
     if dist.is_initialized():
         dist.destroy_process_group()
-    _STATE.update(initialized=False, world=1, rank=0, local_rank=0, backend=None)
+    _STATE.update(initialized=False, world=1, rank=0, local_rank=0, backend=None, plane=None)
 
 
 def size():
@@ -76,6 +266,10 @@ def local_rank():
 
 def is_distributed():
     return _STATE["world"] > 1
+
+
+def data_plane():
+    return _STATE["plane"]
 
 
 def DistributedGradientTape(tape):
@@ -101,16 +295,17 @@ def broadcast_variables(variables, root_rank=0):
     instead of one per variable; refreshes the bf16 shadow afterwards."""
     if not is_distributed():
         return
+    plane = data_plane()
     for kind, obj in _flat_tensors(variables):
         if kind == "arena":
-            dist.broadcast(obj.params, src=root_rank)
+            plane.broadcast(obj.params, root_rank)
             obj.refresh_shadow()
         else:
-            dist.broadcast(obj, src=root_rank)
+            plane.broadcast(obj, root_rank)
 
 
 def allgather_object(y):
-    """hvd.allgather_object (polus/callbacks.py:249): list with one entry per rank."""
+    """hvd.allgather_object (polus/callbacks.py:249): list with one entry per rank (control plane)."""
     if not is_distributed():
         return [y]
     out = [None] * size()
@@ -127,33 +322,71 @@ def barrier():
         dist.barrier()
 
 
-class GradBucketReducer:
-    """Bucketed, backward-overlapped gradient all-reduce over a flat arena."""
+def max_over_ranks(value):
+    """Host scalar -> its maximum over the ranks (bench.py's timing rule)."""
+    if not is_distributed():
+        return value
+    vals = [None] * size()
+    dist.all_gather_object(vals, float(value))
+    return max(vals)
 
-    def __init__(self, grads, bucket_bytes=64 << 20, boundaries=None):
+
+class GradBucketReducer:
+    """Bucketed, backward-overlapped gradient exchange over a flat arena (see the module docstring).
+
+    mode "allreduce": buckets cut at the given tensor `boundaries` (sorted offsets), ~bucket_bytes each.
+    mode "rs": buckets of equal size (a multiple of 64 * world elements, so that every slice is whole
+    256-byte lines), the front bucket takes the remainder; `grads.numel()` must be a multiple of 64 * world
+    (ParamArena pads to that).  `transport_dtype=torch.bfloat16` sends the gradients as bf16."""
+
+    def __init__(self, grads, bucket_bytes=64 << 20, boundaries=None, mode="allreduce", transport_dtype=None, plane=None):
         self.grads = grads
+        self.mode = mode
+        self.plane = plane or data_plane()
+        self.world, self.rank = size(), rank()
         n = grads.numel()
         elems = max(1, bucket_bytes // grads.element_size())
-        # cut at tensor boundaries when given (sorted offsets), from the end of the arena
-        cuts = sorted(set(boundaries or [])) or list(range(0, n, elems))
-        cuts = [c for c in cuts if 0 <= c < n]
-        if not cuts or cuts[0] != 0:
-            cuts = [0] + cuts
-        buckets, hi = [], n
-        lo_idx = len(cuts) - 1
-        while hi > 0:
-            lo = cuts[lo_idx]
-            while lo_idx > 0 and hi - cuts[lo_idx - 1] <= elems:
-                lo_idx -= 1
+        if mode == "rs":
+            q = 64 * self.world
+            assert n % q == 0, f"arena of {n} elements is not a multiple of 64 x world = {q}"
+            step = max(q, elems // q * q)
+            buckets, hi = [], n
+            while hi > 0:
+                lo = hi - step if hi - step >= step // 2 else 0      # no tiny front bucket
+                lo = max(lo, 0)
+                buckets.append((lo, hi))
+                hi = lo
+        else:
+            # cut at tensor boundaries when given (sorted offsets), from the end of the arena
+            cuts = sorted(set(boundaries or [])) or list(range(0, n, elems))
+            cuts = [c for c in cuts if 0 <= c < n]
+            if not cuts or cuts[0] != 0:
+                cuts = [0] + cuts
+            buckets, hi = [], n
+            lo_idx = len(cuts) - 1
+            while hi > 0:
                 lo = cuts[lo_idx]
-            buckets.append((lo, hi))
-            hi = lo
-            lo_idx -= 1
+                while lo_idx > 0 and hi - cuts[lo_idx - 1] <= elems:
+                    lo_idx -= 1
+                    lo = cuts[lo_idx]
+                buckets.append((lo, hi))
+                hi = lo
+                lo_idx -= 1
         self.buckets = buckets          # descending offsets
+        self.transport_dtype = transport_dtype if (transport_dtype is not None and transport_dtype != grads.dtype) else None
+        self._stage = None
         self._next = 0
         self._ready_lo = n
         self._works = []
         self.launched_bytes = 0
+
+    # ---- slices this rank owns after the reduce-scatter: slice `rank` of every bucket
+    def owned_ranges(self):
+        out = []
+        for lo, hi in self.buckets:
+            s = (hi - lo) // self.world
+            out.append((lo + self.rank * s, lo + (self.rank + 1) * s))
+        return sorted(out)
 
     def begin(self):
         self._next, self._ready_lo, self._works = 0, self.grads.numel(), []
@@ -163,25 +396,44 @@ class GradBucketReducer:
         self._ready_lo = min(self._ready_lo, lo)
         self._launch_ready()
 
+    def _launch_one(self, lo, hi):
+        view = self.grads[lo:hi]
+        if self.mode != "rs":
+            self.launched_bytes += view.numel() * view.element_size()
+            return self.plane.all_reduce_sum(view)
+        s = (hi - lo) // self.world
+        mine = self.grads[lo + self.rank * s:lo + (self.rank + 1) * s]
+        if self.transport_dtype is None:
+            self.launched_bytes += view.numel() * view.element_size()
+            return self.plane.reduce_scatter_sum(view, mine)       # in place: recv is slice `rank` of send
+        # bf16 on the wire: cast the bucket, reduce-scatter the copy, cast the owned slice back
+        from . import ops
+        if self._stage is None:
+            self._stage = torch.empty(self.grads.numel(), dtype=self.transport_dtype, device=self.grads.device)
+        st = self._stage[lo:hi]
+        ops.cast(view, st)
+        st_mine = self._stage[lo + self.rank * s:lo + (self.rank + 1) * s]
+        self.launched_bytes += st.numel() * st.element_size()
+        h = self.plane.reduce_scatter_sum(st, st_mine)
+        return _CastBack(h, st_mine, mine)
+
     def _launch_ready(self):
         while self._next < len(self.buckets) and self.buckets[self._next][0] >= self._ready_lo:
             lo, hi = self.buckets[self._next]
-            view = self.grads[lo:hi]
-            # async: the process group's stream waits for the kernels queued so far on the
-            # current stream, then reduces beside whatever backward launches next
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
-            self.launched_bytes += view.numel() * view.element_size()
+            # async: the comm stream waits for the kernels queued so far on the compute stream, then
+            # reduces beside whatever backward launches next
+            self._works.append(self._launch_one(lo, hi))
             self._next += 1
 
     def finish(self, keep_last=False):
         """Flush what is left and make the current stream wait for every bucket.
-        keep_last: leave the last bucket (the front of the arena: the embeddings, whose gradient
-        is the last thing backward produces) in flight and return its upper offset -- the caller
-        updates the parameters above it first and then calls finish_last().  Returns None when
-        there is nothing to keep (a single bucket)."""
+        keep_last (allreduce mode): leave the last bucket (the front of the arena: the embeddings, whose
+        gradient is the last thing backward produces) in flight and return its upper offset -- the caller
+        updates the parameters above it first and then calls finish_last().  Returns None when there is
+        nothing to keep (a single bucket)."""
         self._ready_lo = 0
         self._launch_ready()
-        keep = keep_last and len(self._works) > 1 and self._next == len(self.buckets)
+        keep = keep_last and self.mode != "rs" and len(self._works) > 1 and self._next == len(self.buckets)
         for w in (self._works[:-1] if keep else self._works):
             w.wait()
         self._works = self._works[-1:] if keep else []
@@ -191,3 +443,25 @@ class GradBucketReducer:
         for w in self._works:
             w.wait()
         self._works = []
+
+    def allgather(self, params):
+        """rs mode, after the sharded optimizer step: every rank's updated slices back into the full arena."""
+        assert self.mode == "rs" and params.numel() == self.grads.numel()
+        works = []
+        for lo, hi in self.buckets:
+            s = (hi - lo) // self.world
+            works.append(self.plane.all_gather(params[lo + self.rank * s:lo + (self.rank + 1) * s], params[lo:hi]))
+        for w in works:
+            w.wait()
+
+
+class _CastBack:
+    """wait() of a bf16-transported bucket: after the collective, widen the owned slice into the f32 arena."""
+
+    def __init__(self, handle, src, dst):
+        self.handle, self.src, self.dst = handle, src, dst
+
+    def wait(self):
+        from . import ops
+        self.handle.wait()
+        ops.cast(self.src, self.dst)

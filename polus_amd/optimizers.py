@@ -103,26 +103,36 @@ class Adam:
             self._state[id(arena)] = st
         return st
 
-    def _table(self, arena, variables):
-        key = (id(arena), tuple(id(v) for v in variables))
+    def _table(self, arena, variables, ranges=None):
+        """Device segment table (begin, end, flags) of the windows to update: the variables, cut into
+        chunks, and -- data-parallel sharded update -- intersected with the `ranges` this rank owns."""
+        key = (id(arena), tuple(id(v) for v in variables), tuple(ranges) if ranges is not None else None)
         t = self._tables.get(key)
         if t is None:
             seg = []
             for v in variables:
                 decay = v.decay and not (self.exclude and self.exclude(v.name))
                 flags = (1 if (decay and self.weight_decay_rate) else 0) | (2 if v.matrix else 0)
-                for b in range(v.offset, v.offset + v.size, _CHUNK):
-                    seg.append((b, min(v.offset + v.size, b + _CHUNK), flags))
+                windows = [(v.offset, v.offset + v.size)]
+                if ranges is not None:
+                    windows = [(max(v.offset, lo), min(v.offset + v.size, hi)) for lo, hi in ranges]
+                    windows = [(lo, hi) for lo, hi in windows if hi > lo]
+                for wlo, whi in windows:
+                    for b in range(wlo, whi, _CHUNK):
+                        seg.append((b, min(whi, b + _CHUNK), flags))
+            if not seg:
+                seg = [(0, 0, 0)]
             t = (torch.from_numpy(np.asarray(seg, np.int64)).to(arena.device), len(seg))
             self._tables[key] = t
         return t
 
-    def apply_gradients(self, grads_and_vars, _advance=True, _refresh=True):
+    def apply_gradients(self, grads_and_vars, _advance=True, _refresh=True, _ranges=None):
         """`grads` are the arena gradient windows of the variables (the trainer passes
         ``v.grad``); one fused launch per arena.  `_advance=False` applies the SAME step (count,
         learning rate) to further variables -- the data-parallel trainer updates the encoder while
         the embedding gradients are still being all-reduced; `_refresh=False` postpones the
-        transposed-shadow refresh to that second call."""
+        transposed-shadow refresh to that second call; `_ranges` = the arena windows this rank owns after
+        a gradient reduce-scatter (only those are updated; the parameters are all-gathered afterwards)."""
         variables = [v for _, v in grads_and_vars]
         if _advance:
             self._lr_now = self.learning_rate(self.iterations)
@@ -141,12 +151,12 @@ class Adam:
             sq = torch.empty(len(arenas), dtype=torch.float32, device=dev0)
             clip = torch.empty(1, dtype=torch.float32, device=dev0)
             for k, (arena, vs) in enumerate(arenas.values()):
-                seg, n_seg = self._table(arena, vs)
+                seg, n_seg = self._table(arena, vs, _ranges)
                 ops.sqnorm_segments(arena.grads, seg, n_seg, sq[k:k + 1])
             ops.clip_scale(sq, self.grad_scale, self.global_clipnorm, clip)
         for arena, vs in arenas.values():
             m, v = self._slots(arena)
-            seg, n_seg = self._table(arena, vs)
+            seg, n_seg = self._table(arena, vs, _ranges)
             ops.adam_step(arena.params, arena.grads, m, v, arena.shadow, seg, n_seg, lr, lr_t,
                           self.beta_1, self.beta_2, self.epsilon, self.weight_decay_rate,
                           grad_scale=self.grad_scale, clip_scale=clip)

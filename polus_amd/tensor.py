@@ -142,7 +142,10 @@ class ParamArena:
     def finalize(self):
         if self.params is not None:
             return self
-        from . import ops
+        from . import comm, ops
+        # whole 256-byte lines per rank: a gradient reduce-scatter cuts the arena into `world` equal slices
+        q = ALIGN * max(1, comm.size())
+        self.size = (self.size + q - 1) // q * q
         host = np.zeros(self.size, np.float32)
         for v in self.vars:
             host[v.offset:v.offset + v.size] = np.asarray(v._init, np.float32).reshape(-1)

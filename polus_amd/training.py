@@ -76,12 +76,31 @@ class BaseTrainer:
                 out.append(v.arena)
         return out
 
+    def _dp_mode(self):
+        """How the gradients of this trainer are exchanged (decided once): "rs" = reduce-scatter -> AdamW on
+        the owned slices -> all-gather of the parameters, when one fused optimizer sweeps one arena and
+        nothing needs every gradient on every rank (no post_process_grads, no global-norm clipping);
+        else "allreduce".  POLUS_DP_MODE=allreduce forces the latter."""
+        m = getattr(self, "_dp_mode_cached", None)
+        if m is None:
+            arenas = self._arenas()
+            ok = (len(arenas) == 1 and isinstance(self.optimizer, Adam) and not self.optimizer.global_clipnorm and
+                  self.post_process_grads is None and hasattr(arenas[0], "size") and
+                  arenas[0].grads.numel() % (64 * hvd.size()) == 0 and
+                  all(v.arena is arenas[0] for v in self.trainable_weights) and
+                  os.environ.get("POLUS_DP_MODE", "rs") != "allreduce")
+            m = self._dp_mode_cached = "rs" if ok else "allreduce"
+        return m
+
     def _reducer(self, arena):
         r = self._reducers.get(id(arena))
         if r is None:
+            import torch
             bucket = int(float(os.environ.get("POLUS_BUCKET_MB", "64")) * (1 << 20))
-            r = comm.GradBucketReducer(arena.grads, bucket_bytes=bucket,
-                                       boundaries=[v.offset for v in arena.vars])
+            mode = self._dp_mode()
+            bf16 = os.environ.get("POLUS_DP_BF16", "0") == "1" and mode == "rs" and arena.grads.is_cuda
+            r = comm.GradBucketReducer(arena.grads, bucket_bytes=bucket, boundaries=[v.offset for v in arena.vars],
+                                       mode=mode, transport_dtype=torch.bfloat16 if bf16 else None)
             self._reducers[id(arena)] = r
         return r
 
@@ -100,10 +119,12 @@ class BaseTrainer:
         inputs = self.forward_with_grads(*inputs)
         loss_value = self.loss(*inputs)
 
+        # The exchange starts inside backward: on the micro-step that completes an accumulation the model
+        # reports each gradient window as it becomes final and the reducer fires the buckets above it.
         reducers = []
         if self.use_horovod and last:
             arenas = self._arenas()
-            if len(arenas) == 1 and hasattr(self.model, "grad_ready_hook") and accum == 1:
+            if len(arenas) == 1 and hasattr(self.model, "grad_ready_hook"):
                 r = self._reducer(arenas[0])
                 r.begin()
                 self.model.grad_ready_hook = r.on_ready
@@ -113,29 +134,31 @@ class BaseTrainer:
         if not last:
             return loss_value
 
+        # gradients hold the SUM over ranks and micro-steps; the mean is taken inside the fused optimizer kernel
+        scale = 1.0 / (hvd.size() * accum)
+        split_at, owned = None, None
         if self.use_horovod:
             if not reducers:
                 reducers = [self._reducer(a) for a in self._arenas()]
                 for r in reducers:
                     r.begin()
-            # One arena, a fused optimizer and nothing that needs all gradients at once: keep the last
-            # bucket (the embeddings) in flight and update everything above it meanwhile.
-            can_split = (len(reducers) == 1 and self.post_process_grads is None and accum == 1 and
-                         isinstance(self.optimizer, Adam) and not self.optimizer.global_clipnorm and
-                         os.environ.get("POLUS_DP_SPLIT_ADAM", "1") != "0" and
-                         all(v.arena.grads is reducers[0].grads for v in self.trainable_weights))
-            split_at = reducers[0].finish(keep_last=True) if can_split else None
-            if not can_split:
-                for r in reducers:
-                    r.finish()
+            if self._dp_mode() == "rs":
+                reducers[0].finish()
+                owned = reducers[0].owned_ranges()
+            else:
+                # One arena, a fused optimizer and nothing that needs all gradients at once: keep the last
+                # bucket (the embeddings) in flight and update everything above it meanwhile.
+                can_split = (len(reducers) == 1 and self.post_process_grads is None and
+                             isinstance(self.optimizer, Adam) and not self.optimizer.global_clipnorm and
+                             os.environ.get("POLUS_DP_SPLIT_ADAM", "1") != "0" and
+                             all(v.arena.grads is reducers[0].grads for v in self.trainable_weights))
+                split_at = reducers[0].finish(keep_last=True) if can_split else None
+                if not can_split:
+                    for r in reducers:
+                        r.finish()
             if hasattr(self.model, "grad_ready_hook"):
                 self.model.grad_ready_hook = None
-        else:
-            split_at = None
 
-        # gradients hold the SUM over ranks and micro-steps; the mean is taken inside the
-        # fused optimizer kernel
-        scale = 1.0 / (hvd.size() * accum)
         grads = [v.grad for v in self.trainable_weights]
         if self.post_process_grads is not None:
             if scale != 1.0:
@@ -146,7 +169,13 @@ class BaseTrainer:
             grads = self.post_process_grads(grads)
         if hasattr(self.optimizer, "grad_scale"):
             self.optimizer.grad_scale = scale
-        if split_at is not None:
+        if owned is not None:
+            # every rank updates its slices of the arena, then the updated f32 parameters travel back
+            arena = self._arenas()[0]
+            self.optimizer.apply_gradients(list(zip(grads, self.trainable_weights)), _ranges=owned, _refresh=False)
+            reducers[0].allgather(arena.params)
+            arena.refresh_shadow()
+        elif split_at is not None:
             upper = [v for v in self.trainable_weights if v.offset >= split_at]
             lower = [v for v in self.trainable_weights if v.offset < split_at]
             self.optimizer.apply_gradients([(v.grad, v) for v in upper], _refresh=not lower)

@@ -42,6 +42,29 @@ def main():
     r.finish()
     assert r._next == 4 and torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
 
+    # -- the same arena through reduce-scatter -> update of the owned slices -> all-gather (the "rs" scheme):
+    #    equal buckets of whole 64 x world element units from the end, rank r owns slice r of every bucket
+    n = 64 * 2 * 9
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    r = comm.GradBucketReducer(g, bucket_bytes=4 * 64 * 2 * 2, mode="rs")
+    assert r.buckets[0] == (n - 256, n) and r.buckets[-1][0] == 0 and all((hi - lo) % 128 == 0 for lo, hi in r.buckets)
+    r.begin()
+    r.on_ready(n - 256, n)
+    assert r._next == 1
+    r.on_ready(n - 300, n - 256)                 # not a whole bucket yet
+    assert r._next == 1
+    r.finish()
+    owned = r.owned_ranges()
+    assert sum(hi - lo for lo, hi in owned) == n // 2
+    full = torch.arange(n, dtype=torch.float32) * 3
+    for lo, hi in owned:
+        assert torch.equal(g[lo:hi], full[lo:hi]), (lo, hi)
+    p = torch.full((n,), -1.0)
+    for lo, hi in owned:                          # "optimizer step" on the owned slices only
+        p[lo:hi] = -0.5 * g[lo:hi]
+    r.allgather(p)
+    assert torch.equal(p, -0.5 * full)
+
     # -- data parallel == large batch, with the oracle as the per-rank compute
     cfg = ob.BertConfig(40, 64, 1, 1, 128, 16, 2)
     params, hw, hb = ob.golden_setup(cfg, 3)

@@ -13,6 +13,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1]
+    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # rs | allreduce | rs_bf16 | rs_accum2
+    os.environ["POLUS_DP_MODE"] = "allreduce" if mode == "allreduce" else "rs"
+    if mode == "rs_bf16":
+        os.environ["POLUS_DP_BF16"] = "1"
     from polus_amd import comm
     from polus_amd.context import PolusContext
     from polus_amd.data import shard
@@ -34,21 +38,32 @@ def main():
     opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps, 1e-3), weight_decay_rate=0.01)
     trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
     assert trainer.use_horovod
+    accum = 2 if mode == "rs_accum2" else 1
+    trainer.grad_accum_steps = accum
     os.environ["POLUS_BUCKET_MB"] = "0.05"        # several buckets even for this small model
     mine = list(shard(range(4), 2, rank))                  # sample i -> rank i mod 2
     batches = []
     for s in range(steps):
         ids, mask, tt, labels = synth_batch(ocfg, 4, 16, 4, 420 + s)
-        batches.append(({"input_ids": ids[mine], "attention_mask": mask[mine], "token_type_ids": tt[mine]},
-                        labels[mine]))
+        for part in ([mine] if accum == 1 else [[m] for m in mine]):       # accumulation: one sample per micro-step
+            batches.append(({"input_ids": ids[part], "attention_mask": mask[part], "token_type_ids": tt[part]},
+                            labels[part]))
     calls = []
     orig = opt.apply_gradients
     opt.apply_gradients = lambda gv, **kw: (calls.append((len(list(gv)) if not isinstance(gv, list) else len(gv), kw)), orig(gv, **kw))[1]
     trainer.train(batches, epochs=1, callbacks=[])
-    # the update is split around the last all-reduce bucket: two launches per step, every variable once
-    assert len(calls) == 2 * steps and all(calls[2 * k][0] + calls[2 * k + 1][0] == len(trainer.trainable_weights)
-                                           for k in range(steps)), calls
-    assert all(calls[2 * k + 1][1].get("_advance") is False for k in range(steps))
+    assert trainer._dp_mode() == ("allreduce" if mode == "allreduce" else "rs")
+    if mode == "allreduce":
+        # the update is split around the last all-reduce bucket: two launches per step, every variable once
+        assert len(calls) == 2 * steps and all(calls[2 * k][0] + calls[2 * k + 1][0] == len(trainer.trainable_weights)
+                                               for k in range(steps)), calls
+        assert all(calls[2 * k + 1][1].get("_advance") is False for k in range(steps))
+    else:
+        # one launch per optimizer step, on the windows this rank owns after the reduce-scatter
+        assert len(calls) == steps and all(c[1].get("_ranges") for c in calls), calls
+        r = trainer._reducer(model.arena)
+        assert len(r.buckets) > 1 and sum(hi - lo for lo, hi in r.owned_ranges()) == model.arena.grads.numel() // 2
+        assert opt.iterations == steps
     # the parent compares parameters, which depend on every step's averaged gradients
     flat = model.arena.params.detach().float().cpu().numpy()
     np.save(f"{out}.rank{rank}.npy", flat)

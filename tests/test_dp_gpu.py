@@ -1,7 +1,10 @@
 """GPU: data parallelism end to end on the real kernels.  Two ranks share the box's one GPU
 (gloo wire, see dp_gpu_worker.py); after 3 AdamW steps on disjoint halves of each batch their
 parameters must equal single-process training on the whole batch at LR x 2
-(polus/training.py:90-94 multiplies the LR by the world size; gradients are averaged)."""
+(polus/training.py:90-94 multiplies the LR by the world size; gradients are averaged) -- for both exchange
+schemes (reduce-scatter -> sharded AdamW -> all-gather, and all-reduce), with gradient accumulation, and
+with bf16 gradient transport.  test_native_rccl_plane_world_1 drives every polus_comm_* entry point on a real
+RCCL communicator (world size 1: the box has one GPU)."""
 import os
 import subprocess
 import sys
@@ -15,7 +18,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
+@pytest.mark.parametrize("mode", ["rs", "allreduce", "rs_accum2", "rs_bf16"])
+def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
     from polus_amd.losses import SparseCategoricalCrossentropy
     from polus_amd.optimizers import AdamWeightDecay
     from polus_amd.schedulers import warmup_scheduler
@@ -29,7 +33,7 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port, POLUS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_gpu_worker.py"), out],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_gpu_worker.py"), out, mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -58,9 +62,45 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path):
     trainer.train(batches, epochs=1, callbacks=[])
     single = model.arena.params.detach().float().cpu().numpy()
     moved = np.abs(single - start).max()
-    diff = np.abs(single - r0)
+    n = min(single.size, r0.size)              # the 2-rank arena is padded to whole 64 x world element units
+    assert not r0[n:].any() and not single[n:].any()
+    diff = np.abs(single[:n] - r0[:n])
     # f32 sums in a different order (two half-batch gradients added on the wire vs one batch-4 GEMM);
     # Adam normalises by sqrt(v), so elements whose gradient is a near-cancelling sum carry the
     # largest relative noise: bound the worst element at 2 % of the largest move and the mean far below.
     assert moved > 1e-3
-    assert diff.max() < 0.02 * moved and diff.mean() < 1e-3 * moved, (diff.max(), diff.mean(), moved)
+    if mode == "rs_bf16":      # gradients rounded to bf16 on the wire: Adam's sign-like first steps amplify it
+        assert diff.mean() < 0.05 * moved, (diff.max(), diff.mean(), moved)
+    else:
+        assert diff.max() < 0.02 * moved and diff.mean() < 1e-3 * moved, (diff.max(), diff.mean(), moved)
+
+
+def test_native_rccl_plane_world_1():
+    """The C-ABI collectives (include/polus_hip.h polus_comm_*) on a real RCCL communicator of size 1: id,
+    init, all-reduce, reduce-scatter, all-gather (in place, as the reducer issues them), broadcast, destroy --
+    queued on a side stream and fenced with events exactly as comm._NativePlane does for N ranks."""
+    import ctypes
+    import torch
+    from polus_amd import _lib
+    from polus_amd.comm import _NativePlane
+    lib = _lib.load()
+    uid = (ctypes.c_ubyte * 128)()
+    _lib.check(lib.polus_comm_unique_id(uid), "polus_comm_unique_id")
+    assert any(uid), "unique id is all zeros"
+    plane = _NativePlane.__new__(_NativePlane)
+    plane.lib, plane.check = lib, _lib.check
+    plane.comm = ctypes.c_void_p()
+    _lib.check(lib.polus_comm_init(ctypes.byref(plane.comm), 0, 1, uid), "polus_comm_init")
+    plane.stream, plane.world, plane.rank = torch.cuda.Stream(), 1, 0
+    x = torch.arange(1 << 16, dtype=torch.float32, device="cuda")
+    ref = x.clone()
+    plane.all_reduce_sum(x).wait()
+    plane.reduce_scatter_sum(x, x).wait()
+    plane.all_gather(x, x).wait()
+    plane.broadcast(x, 0)
+    h = torch.arange(4096, dtype=torch.float32, device="cuda").to(torch.bfloat16)
+    plane.all_reduce_sum(h).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and torch.equal(h.float(), torch.arange(4096, dtype=torch.float32, device="cuda").to(torch.bfloat16).float())
+    assert lib.polus_comm_broadcast(plane.comm, x.data_ptr(), 16, 3, None) != 0 and b"bad root" in lib.polus_last_error()
+    plane.close()
