@@ -146,6 +146,8 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
     model, trainer = build_trainer(args, dtype, args.dropout, max(1000, steps + warmup))
     if ctx.is_horovod_enabled():
         trainer.broadcast_init_vars()
+    if getattr(args, "graph", False) and world == 1:
+        trainer.enable_step_graph(warmup=min(3, max(1, warmup - 1)))
     batches = device_batches(B, S, rank, model.arena.device)
 
     def one_step(k):
@@ -256,6 +258,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the reference-precision (f32 engine) leg")
     ap.add_argument("--no-loss100", action="store_true", help="skip the 2 x 100-step loss@step100 runs")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (launch-bound shapes, one GPU)")
     args = ap.parse_args()
 
     import torch

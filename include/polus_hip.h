@@ -53,6 +53,15 @@ int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len
 /* The POLUS_* tuning switches of the library are read from the environment once, at the first call
  * that needs one; this re-reads them (A/B tools and tests that flip a switch inside one process). */
 int polus_reload_env(void);
+/* Per-step scalars from device memory, for steps replayed from a captured HIP graph (the kernel arguments of a
+ * replay are frozen).  `dev_block16` points to 16 bytes in HBM, {uint32 salt; float lr; float lr_t; uint32 0},
+ * that the caller rewrites before each replay; NULL unregisters.  While a block is registered
+ *   - every dropout site uses seed_eff = mix(seed + salt), mix(x) = (x ^ x >> 15) * 0x2C1B3C6D (uint32), so the
+ *     caller passes the step-independent part as `seed` and the step term as `salt` (the eager path passes
+ *     mix(step-independent + step term) as `seed`: identical masks either way);
+ *   - polus_adam_step takes lr and lr_t from the block instead of its arguments.
+ * Process-wide (one process drives one GPU). */
+int polus_set_dynamic_params(const void* dev_block16);
 
 /* ---- GEMM (HF Dense layers + their gradients; tape.gradient at polus/training.py:185)
  * C[M,N] = epilogue(alpha * A_op[M,K] . B_op[K,N]).

@@ -115,6 +115,7 @@ struct AttnArgs {
     float scale;
     unsigned drop_thresh, drop_seed;   // attention-probability dropout; mask index ((b*A+h)*S+q)*S+key
     float drop_inv;
+    const PolusDyn* dyn;               // per-step scalars in device memory (graph replay) or null
 };
 
 __device__ __forceinline__ float key_bias(const int32_t* mask, int b, int S, int key) {
@@ -129,6 +130,7 @@ __device__ __forceinline__ float key_bias(const int32_t* mask, int b, int S, int
 // 4-wave form pays a global-load latency and two barriers per 64 keys, which is what bounds it).
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     constexpr int QB = 16 * NW, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kc = smem;
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 // ---------------------------------------------------------------- dQ
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     constexpr int QB = 16 * NW, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kc = smem;
@@ -326,7 +329,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // ---------------------------------------------------------------- dK, dV
 template <typename T>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kernel(AttnArgs p) {   // bf16: 3 waves per SIMD (<= 168 registers)
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kernel(AttnArgs p) {
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);   // bf16: 3 waves per SIMD (<= 168 registers)
     // Q and dO are staged QCH query rows per load + barrier pair (bf16: 128, i.e. two 64-row blocks)
     constexpr int QCH = sizeof(T) == 2 ? 2 * BLK : BLK;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QCH * TileCfg<T>::RS + 2 * QCH * 4];
@@ -473,7 +477,7 @@ extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* ma
     POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)B * n_heads * S * S < (1LL << 32), "polus_attention_fwd: bad dropout arguments");
     a.qkv = qkv; a.mask = mask; a.ctx = ctx; a.lse = lse;
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
-    a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p);
+    a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p); a.dyn = polus_dyn();
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc2 = launch_wide<0>(dtype, a, st);
     if (rc2 != POLUS_OK) return rc2;
@@ -501,7 +505,7 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
     a.delta = static_cast<const float*>(workspace);
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
     POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "polus_attention_bwd: bad drop_p");
-    a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p);
+    a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p); a.dyn = polus_dyn();
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((S + BLK - 1) / BLK, n_heads, B);
     if (dtype == POLUS_BF16) {

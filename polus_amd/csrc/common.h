@@ -43,6 +43,22 @@ struct PolusCfg {
 };
 const PolusCfg& polus_cfg();
 
+// ---------------------------------------------------------------- per-step scalars in device memory
+// A captured HIP graph replays the SAME kernel arguments every step, so what changes from step to step --
+// the dropout seeds, the learning rate -- must come from memory.  polus_set_dynamic_params() registers a
+// device block {salt, lr, lr_t, 0}; while it is set every launcher passes it on, and a kernel computes
+//     seed_eff = mix(seed + salt),  mix(x) = (x ^ x >> 15) * 0x2C1B3C6D
+// -- the host computes exactly mix(linear seed + step term) when no block is registered
+// (polus_amd/models.py dropout_seed), so eager and graph-replayed steps draw the same masks.
+struct PolusDyn { uint32_t salt; float lr, lr_t; uint32_t pad; };
+const PolusDyn* polus_dyn();          // the registered block (device pointer) or null
+__device__ __forceinline__ uint32_t polus_eff_seed(uint32_t seed, const PolusDyn* dyn) {
+    if (!dyn) return seed;
+    uint32_t x = seed + dyn->salt;
+    x ^= x >> 15;
+    return x * 0x2C1B3C6Du;
+}
+
 // ---------------------------------------------------------------- scalar conversions
 template <typename T> __device__ __forceinline__ float to_f(T x);
 template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }

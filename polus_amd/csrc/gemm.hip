@@ -138,6 +138,7 @@ __device__ __forceinline__ void frag_ks(Frag<float>& f, const unsigned char* til
 
 template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC, bool DROP>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs p) {
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BK = Cfg<T>::BK, NSUB = Cfg<T>::NSUB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -378,6 +379,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.bias = bias; a.resid = resid; a.ldr = ldr; a.aux = aux; a.ldaux = ldaux;
     a.act = act; a.flags = flags;
     a.drop_inv = 1.0f / (1.0f - drop_p); a.drop_thresh = polus_drop_thresh(drop_p); a.drop_seed = seed;
+    a.dyn = polus_dyn();
     a.partial = split_k > 1 ? static_cast<float*>(workspace) : nullptr;
     const int epc = (int)(16 / es);
     // whole-chunk validity: the contiguous extent of each operand must be a multiple of a chunk

@@ -23,6 +23,8 @@ struct GemmArgs {
     float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
+    const PolusDyn* dyn;  // per-step scalars in device memory (graph replay) or null: kernels with a dropout epilogue
+                          // replace drop_seed by polus_eff_seed(drop_seed, dyn) on entry
 };
 
 template <typename TC> __device__ __forceinline__ void ld4x(const TC* p, float (&v)[4], int vec, int nvalid) {

@@ -69,6 +69,7 @@ template <int TN> struct Cfg {
 
 template <typename TC, int TN, bool DROP, int MODE, int ABL = 0>
 __global__ __launch_bounds__(NTHR, 1) void gemm_p_kernel(GemmArgs p) {
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     typedef Cfg<TN> CF;
     constexpr int NT = CF::NT, NB = CF::NB, ND = CF::ND, STAGE = CF::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

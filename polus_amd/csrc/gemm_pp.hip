@@ -66,6 +66,7 @@ template <int NT> struct PPCfg {
 template <int NT, bool DROP, int MODE, int ABL = 0>
 __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     typedef PPCfg<NT> C;
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     constexpr int WN = C::WN, TN = C::TN, NB = C::NB, STAGE = C::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;

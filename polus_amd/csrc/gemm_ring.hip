@@ -215,6 +215,7 @@ __device__ __forceinline__ void ring_body(const GemmArgs& p, const int wg_in, co
 
 template <typename TC, bool A_KS, bool B_KS, bool DROP, int MODE = -1>
 __global__ __launch_bounds__(NTHR, 2) void gemm_ring_kernel(GemmArgs p) {
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     ring_body<TC, A_KS, B_KS, DROP, MODE>(p, blockIdx.x, gridDim.x, blockIdx.y);
 }
 

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const T* __restrict_
     }
 }
 
-struct DropArgs { unsigned thresh, seed; float inv; };   // thresh == 0: no dropout
+struct DropArgs { unsigned thresh, seed; float inv; const PolusDyn* dyn = nullptr; };   // thresh == 0: no dropout; dyn: see common.h
 
 // Shared tail of the LN backward kernels: given x-hat pieces and dy for one row, produce dx
 // and accumulate the per-feature sums.
@@ -227,6 +227,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void ln_bwd_kernel(const T* __restr
                                                      const float* __restrict__ rstd, T* __restrict__ dx,
                                                      float* __restrict__ partial, int rows, int H, int want_bias,
                                                      T* __restrict__ dxm, DropArgs drop) {
+    if (drop.thresh) drop.seed = polus_eff_seed(drop.seed, drop.dyn);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -374,7 +375,8 @@ __global__ __launch_bounds__(LN_THREADS) void embed_fwd_kernel(const int32_t* __
                                                         const float* __restrict__ beta, T* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                         int B, int S, int H, int vocab, int type_vocab, float eps,
-                                                        unsigned dthresh, unsigned dseed, float dinv) {
+                                                        unsigned dthresh, unsigned dseed, float dinv, const PolusDyn* dyn) {
+    if (dthresh) dseed = polus_eff_seed(dseed, dyn);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int rows = B * S;
     float gv[NC][4], bv[NC][4];
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(LN_THREADS) void embed_bwd_ln_kernel(const T* __res
                                                            const float* __restrict__ rstd, float* __restrict__ de,
                                                            float* __restrict__ partial, int B, int S, int H, int vocab,
                                                            int type_vocab, DropArgs in_drop) {
+    if (in_drop.thresh) in_drop.seed = polus_eff_seed(in_drop.seed, in_drop.dyn);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -525,7 +528,7 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
     POLUS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "polus_layernorm_bwd: null pointer");
     POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)rows * H < (1LL << 32), "polus_layernorm_bwd: bad dropout arguments");
     POLUS_REQUIRE(!(drop_p > 0.f) || dx_masked, "polus_layernorm_bwd: dropout needs dx_masked");
-    DropArgs drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p)};
+    DropArgs drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p), polus_dyn()};
     POLUS_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 256 * MAXC, "polus_layernorm_bwd: bad H=%d", H);
     POLUS_REQUIRE(polus_aligned16(x) && polus_aligned16(dy) && polus_aligned16(dx) && polus_aligned16(gamma),
                   "polus_layernorm_bwd: pointers must be 16-byte aligned");
@@ -601,9 +604,9 @@ extern "C" int polus_embed_ln_fwd(int dtype, const int32_t* ids, const int32_t* 
     int rows = B * S, blocks = (rows + WAVES - 1) / WAVES;
     if (blocks > 4096) blocks = 4096;
     if (dtype == POLUS_BF16)
-        POLUS_NC_DISPATCH(H, bf16_t, embed_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, ids, type_ids, word, pos, type, gamma, beta, (bf16_t*)y, mean, rstd, B, S, H, vocab, type_vocab, eps, dthresh, seed, dinv);
+        POLUS_NC_DISPATCH(H, bf16_t, embed_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, ids, type_ids, word, pos, type, gamma, beta, (bf16_t*)y, mean, rstd, B, S, H, vocab, type_vocab, eps, dthresh, seed, dinv, polus_dyn());
     else if (dtype == POLUS_F32)
-        POLUS_NC_DISPATCH(H, float, embed_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, ids, type_ids, word, pos, type, gamma, beta, (float*)y, mean, rstd, B, S, H, vocab, type_vocab, eps, dthresh, seed, dinv);
+        POLUS_NC_DISPATCH(H, float, embed_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, ids, type_ids, word, pos, type, gamma, beta, (float*)y, mean, rstd, B, S, H, vocab, type_vocab, eps, dthresh, seed, dinv, polus_dyn());
     else POLUS_FAIL("polus_embed_ln_fwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_embed_ln_fwd");
     return POLUS_OK;
@@ -617,7 +620,7 @@ extern "C" int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids,
                                   int B, int S, int H, int vocab, int max_pos, int type_vocab,
                                   float drop_p, uint32_t seed,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-    DropArgs in_drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p)};
+    DropArgs in_drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p), polus_dyn()};
     POLUS_REQUIRE(dy && ids && word && pos && type && gamma && mean && rstd && gword && gpos && gtype && ggamma && gbeta,
                   "polus_embed_ln_bwd: null pointer");
     POLUS_REQUIRE(B > 0 && S > 0 && S <= max_pos && H % 4 == 0 && H <= 256 * MAXC, "polus_embed_ln_bwd: bad shape");

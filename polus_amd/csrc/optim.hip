@@ -13,9 +13,11 @@ struct AdamArgs {
     const int64_t* seg; int n_seg;
     float lr, lr_t, b1, b2, eps, wd, gscale;
     const float* clip;
+    const PolusDyn* dyn;   // graph replay: lr and lr_t of this step come from device memory
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    if (a.dyn) { a.lr = a.dyn->lr; a.lr_t = a.dyn->lr_t; }
     const float gs = a.gscale * (a.clip ? *a.clip : 1.0f);
     for (int s = blockIdx.x; s < a.n_seg; s += gridDim.x) {
         const int64_t beg = a.seg[3 * s], end = a.seg[3 * s + 1], flags = a.seg[3 * s + 2];
@@ -137,6 +139,7 @@ extern "C" int polus_adam_step(float* p, const float* g, float* m, float* v, voi
     AdamArgs a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.shadow = static_cast<bf16_t*>(shadow_bf16);
     a.seg = seg; a.n_seg = n_seg;
+    a.dyn = polus_dyn();
     a.lr = lr; a.lr_t = lr_t; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
     a.gscale = grad_scale; a.clip = clip_scale;
     int blocks = n_seg < 4096 ? n_seg : 4096;

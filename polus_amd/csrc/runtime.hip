@@ -36,6 +36,14 @@ const PolusCfg& polus_cfg() {
     return g_cfg;
 }
 extern "C" int polus_reload_env(void) { read_cfg(); return POLUS_OK; }
+
+static const PolusDyn* g_dyn = nullptr;
+const PolusDyn* polus_dyn() { return g_dyn; }
+extern "C" int polus_set_dynamic_params(const void* dev_block16) {
+    POLUS_REQUIRE(dev_block16 == nullptr || polus_aligned16(dev_block16), "polus_set_dynamic_params: the block must be 16-byte aligned");
+    g_dyn = static_cast<const PolusDyn*>(dev_block16);
+    return POLUS_OK;
+}
 extern "C" int polus_abi_version(void) { return POLUS_ABI_VERSION; }
 
 extern "C" int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len) {
@@ -170,13 +178,17 @@ __global__ __launch_bounds__(256) void transpose16_batched_kernel(const unsigned
 }
 
 template <typename T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, unsigned seed, unsigned thresh, float inv) {
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, unsigned seed, unsigned thresh, float inv,
+                               const PolusDyn* dyn) {
+    seed = polus_eff_seed(seed, dyn);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) y[i] = polus_keep(seed, (unsigned)i, thresh) ? from_f<T>(to_f<T>(x[i]) * inv) : from_f<T>(0.f);
 }
 
-__global__ void dropout_mask_kernel(unsigned seed, unsigned thresh, unsigned idx0, int64_t n, uint8_t* __restrict__ mask) {
+__global__ void dropout_mask_kernel(unsigned seed, unsigned thresh, unsigned idx0, int64_t n, uint8_t* __restrict__ mask,
+                                    const PolusDyn* dyn) {
+    seed = polus_eff_seed(seed, dyn);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) mask[i] = polus_keep(seed, idx0 + (unsigned)i, thresh) ? 1 : 0;
@@ -261,7 +273,7 @@ extern "C" int polus_dropout_mask(uint32_t seed, float drop_p, uint32_t idx0, in
     int64_t b = (n + 255) / 256;
     if (b > 4096) b = 4096;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)b), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       seed, polus_drop_thresh(drop_p), idx0, n, mask);
+                       seed, polus_drop_thresh(drop_p), idx0, n, mask, polus_dyn());
     POLUS_CHECK_LAUNCH("polus_dropout_mask");
     return POLUS_OK;
 }
@@ -274,8 +286,8 @@ extern "C" int polus_dropout(int dtype, const void* x, void* y, int64_t n, float
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned th = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u;
     const float inv = 1.0f / (1.0f - drop_p);
-    if (dtype == POLUS_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((int)b), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n, seed, th, inv);
-    else if (dtype == POLUS_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((int)b), dim3(256), 0, st, (const float*)x, (float*)y, n, seed, th, inv);
+    if (dtype == POLUS_BF16) hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((int)b), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n, seed, th, inv, polus_dyn());
+    else if (dtype == POLUS_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((int)b), dim3(256), 0, st, (const float*)x, (float*)y, n, seed, th, inv, polus_dyn());
     else POLUS_FAIL("polus_dropout: bad dtype");
     POLUS_CHECK_LAUNCH("polus_dropout");
     return POLUS_OK;

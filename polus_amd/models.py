@@ -117,12 +117,27 @@ class BaseModelOutputWithPooling:
         return getattr(self, k)
 
 
+_M32 = 0xFFFFFFFF
+
+
+def dropout_seed_static(base, layer, site):
+    """The step-independent part of a dropout site's seed (sites: 0 attention probs, 1 attention output,
+    2 FFN output; layer -1 = embeddings)."""
+    return (base * 0x9E3779B1 + ((layer + 1) * 8 + site) * 0xC2B2AE35) & _M32
+
+
+def dropout_salt(step):
+    """The per-step part: seed = mix(static + salt), mix(x) = (x ^ x >> 15) * 0x2C1B3C6D (uint32)."""
+    return (step * 0x85EBCA6B) & _M32
+
+
 def dropout_seed(base, step, layer, site):
-    """32-bit seed of one dropout site of one step (sites: 0 attention probs, 1 attention output,
-    2 FFN output; layer -1 = embeddings).  The kernels hash (seed, element index)."""
-    x = (base * 0x9E3779B1 + step * 0x85EBCA6B + ((layer + 1) * 8 + site) * 0xC2B2AE35) & 0xFFFFFFFF
+    """32-bit seed of one dropout site of one step.  The kernels hash (seed, element index).  When a step is
+    replayed from a HIP graph the kernels do the final mix themselves from the static part and a salt in
+    device memory (include/polus_hip.h polus_set_dynamic_params): same masks either way."""
+    x = (dropout_seed_static(base, layer, site) + dropout_salt(step)) & _M32
     x ^= x >> 15
-    return (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    return (x * 0x2C1B3C6D) & _M32
 
 
 def _trunc_normal(rng, shape, std=0.02):
@@ -474,6 +489,8 @@ class BertModel(SavableModel):
             from . import comm
             if comm.size() > 1:
                 base = (base ^ (comm.rank() * 0x9E3779B1)) & 0xFFFFFFFF
+        if getattr(self, "graph_seeds", False):     # the step term comes from device memory (polus_amd/graph.py)
+            return dropout_seed_static(base, layer, site)
         return dropout_seed(base, self.dropout_step if step is None else step, layer, site)
 
     def encode(self, hidden, attention_mask, B, S, training=False):

@@ -35,6 +35,7 @@ class Workspace:
 
 
 _WS = {}
+WORKSPACE_OVERRIDE = None      # polus_amd/graph.py: the scratch a captured step uses (same buffer in every replay)
 
 
 _HAS_GPU = None
@@ -42,6 +43,8 @@ _HAS_GPU = None
 
 def workspace(device):
     global _HAS_GPU
+    if WORKSPACE_OVERRIDE is not None:
+        return WORKSPACE_OVERRIDE
     if _HAS_GPU is None:
         _HAS_GPU = torch.cuda.is_available()      # ~20 us per call otherwise, once per launch
     key = (device, _lib.current_stream() if _HAS_GPU else 0)
@@ -53,6 +56,15 @@ def workspace(device):
 
 def _st():
     return _lib.current_stream()
+
+
+def set_dynamic_params(block):
+    """Register (None: unregister) the 16-byte device block {uint32 salt, f32 lr, f32 lr_t, 0} that dropout
+    kernels and the fused optimizer read per-step scalars from (include/polus_hip.h)."""
+    if block is not None:
+        _req_cuda(block)
+        assert block.numel() * block.element_size() >= 16 and block.is_contiguous()
+    check(_lib.load().polus_set_dynamic_params(ptr(block)), "polus_set_dynamic_params")
 
 
 def set_env(name, value=None):

@@ -107,8 +107,24 @@ class BaseTrainer:
     def train_step(self, *inputs):
         """polus/training.py:150-193, same order: forward_without_grads -> forward_with_grads
         -> loss -> gradients (all-reduced across ranks) -> post_process_grads -> apply."""
+        g = getattr(self, "_graphed", None)
+        if g is not None:
+            return g(*inputs)
+        return self._eager_step(*inputs)
+
+    def _eager_step(self, *inputs):
         with _lib.pinned_stream():      # one stream lookup per step instead of one per launch
             return self._train_step(*inputs)
+
+    def enable_step_graph(self, warmup=3):
+        """Replay the step from a captured HIP graph after `warmup` eager steps (polus_amd/graph.py): for
+        launch-bound workloads.  Same results bit for bit; single process, static batch shape."""
+        from .graph import GraphedStep
+        self._graphed = GraphedStep(self, warmup)
+        return self
+
+    def disable_step_graph(self):
+        self._graphed = None
 
     def _train_step(self, *inputs):
         micro = self.step_counter_micro = getattr(self, "step_counter_micro", 0)

@@ -300,3 +300,44 @@ def test_loss_scalars_are_independent_values():
         kept.append(loss_fn(labels, dev(logits)))
         ref.append(ol.sparse_softmax_xent_fwd(logits.astype(np.float64), labels)[0])
     assert np.allclose([float(k) for k in kept], ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_graphed_step_equals_eager_step_bitwise(mode):
+    """trainer.enable_step_graph(): after the eager warm-up steps the step is replayed from a captured HIP
+    graph with the dropout salt and AdamW's lr / lr_t read from device memory -- same masks, same schedule:
+    losses and parameters equal the eager run bit for bit, over the capture boundary and a changing batch."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import BertConfig, BertModel
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.schedulers import warmup_scheduler
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    g, ocfg, params, hw, hb = load_case("bert_small_b3_s48")
+    steps = 9
+
+    def run(graphed):
+        cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                         ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size,
+                         hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        m = BertModel(cfg, compute_dtype=mode, num_labels=hw.shape[0])
+        m.load_numpy_params(params, hw, hb)
+        m.deterministic = True
+        t = ClassifierTrainer(m, AdamWeightDecay(learning_rate=warmup_scheduler(steps, 1e-3), weight_decay_rate=0.01),
+                              SparseCategoricalCrossentropy(grad_dtype=m.compute_dtype))
+        if graphed:
+            t.enable_step_graph(warmup=2)
+        losses = []
+        for s in range(steps):
+            ids, mask, tt, labels = synth_batch(ocfg, 3, 48, 4, 500 + s)
+            losses.append(t.train_step({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels))
+        out = [float(l) for l in losses]          # read late: every step kept its own scalar
+        torch.cuda.synchronize()
+        if graphed:
+            assert t._graphed.graph is not None and m.dropout_step == steps and t.optimizer.iterations == steps
+        return out, m.arena.params.clone()
+    eager, p_eager = run(False)
+    graphed, p_graph = run(True)
+    assert eager == graphed, (eager, graphed)
+    assert torch.equal(p_eager, p_graph)
+    assert eager[-1] < eager[0]
