@@ -427,6 +427,164 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kern
     store_acc_T<T>(dqkv, ld, key, 2 * H + h * D, dv, 1.0f, g, kvalid);
 }
 
+// ---------------------------------------------------------------- backward in ONE pass (bf16, S in {64, 128, 256})
+// One workgroup per (batch, head), S/16 waves, everything of the head on chip: Q and dO (all S rows) in LDS,
+// K / V streamed in blocks of 32 keys (double-buffered).  Per key block:
+//   phase 1  wave w owns queries 16w..16w+15 (as in the dQ kernel): S^T and dP^T tiles [32 keys x 16 queries] on
+//            the matrix pipe, then -- ONCE per score -- the exponential, the dropout mask and dS; dQ^T += K^T dS^T
+//            straight from the registers; the dropped probabilities P' and dS go to LDS as bf16 [query][key];
+//   phase 2  the 16 output tiles of the block (dK^T and dV^T, [64 d x 32 keys] each) are dealt to the waves:
+//            dK^T[d][key] = sum over ALL queries of Q^T[d][q] dS[q][key], dV^T = dO^T P', both operands by
+//            transposing LDS reads with the same k (= query) order, final after S/32 MFMAs, stored at once.
+// The two-kernel form evaluates every score twice (once per orientation of the S x S matrix: ~30 VALU
+// lane-operations per score each time, against 7 matrix products it is VALU time that bounds it); here the
+// second orientation costs an LDS round trip of two bf16 tiles instead.  Atomics-free, fixed summation order.
+constexpr int KBLK = 32, RSS = 80;     // keys per block; row stride of the P' / dS staging tiles (64 B + pad)
+
+__device__ __forceinline__ void frag_tr_rs(Frag<bf16_t>& f, const unsigned char* tile, int rs, int kb, int c0, int i, int g) {
+    const unsigned char* p = tile + (kb + 4 * g + (i >> 2)) * rs + (c0 + 4 * (i & 3)) * 2;
+    s16x4 lo = lds_tr16(p);
+    s16x4 hi = lds_tr16(p + 16 * rs);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = __builtin_bit_cast(bf16x8, w);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
+    typedef bf16_t T;
+    constexpr int S = 16 * NW, NT = 64 * NW, RS = TileCfg<T>::RS, NKB = S / KBLK, TPW = 16 / NW;
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Qc = smem;
+    unsigned char* Oc = Qc + S * RS;
+    unsigned char* Kc = Oc + S * RS;                  // [2][KBLK][RS]
+    unsigned char* Vc = Kc + 2 * KBLK * RS;           // [2][KBLK][RS]
+    unsigned char* Ps = Vc + 2 * KBLK * RS;           // [S][RSS]
+    unsigned char* Ds = Ps + S * RSS;                 // [S][RSS]
+    float* kbc = reinterpret_cast<float*>(Ds + S * RSS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int H = p.H;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const T* dctx = static_cast<const T*>(p.dctx) + (long)b * S * H;
+    T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
+    const int q = wid * 16 + i;
+
+    auto load_kv = [&](int kb, int buf) {          // 32 keys x (K | V) x 8 chunks of 16 B
+        for (int c = tid; c < 2 * KBLK * 8; c += NT) {
+            const int which = c >> 8, cc = c & 255, r = cc >> 3, ch = cc & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(qkv + (long)(kb * KBLK + r) * ld + (1 + which) * H + h * D + ch * 8);
+            *reinterpret_cast<uint4*>((which ? Vc : Kc) + (buf * KBLK + r) * RS + ch * 16) = v;
+        }
+    };
+    tile_load<T, NT>(Qc, qkv, ld, 0, S, h * D, tid);
+    tile_load<T, NT>(Oc, dctx, H, 0, S, h * D, tid);
+    load_kv(0, 0);
+    if (tid < S) kbc[tid] = key_bias(p.mask, b, S, tid) * LOG2E;
+
+    Frag<T> qf[2], dof[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        frag_global<T>(qf[sub], qkv + (long)q * ld + h * D + sub * 32 + 8 * g, true);
+        frag_global<T>(dof[sub], dctx + (long)q * H + h * D + sub * 32 + 8 * g, true);
+    }
+    const long stat = ((long)b * p.A + h) * S + q;
+    const float lse2 = p.lse[stat] * LOG2E;
+    const float scale2 = p.scale * LOG2E;
+    float dl = 0.f;                                   // delta = rowsum(dO * O) of this query's head
+    {
+        const T* ctx = static_cast<const T*>(p.ctx) + (long)b * S * H;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            Frag<T> of;
+            frag_global<T>(of, ctx + (long)q * H + h * D + sub * 32 + 8 * g, true);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of.v[j] * (float)dof[sub].v[j];
+        }
+        dl = col_sum(dl);
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int kb = 0; kb < NKB; ++kb) {
+        const int cur = kb & 1;
+        const unsigned char* Kt = Kc + cur * KBLK * RS;
+        const unsigned char* Vt = Vc + cur * KBLK * RS;
+        if (kb + 1 < NKB) load_kv(kb + 1, cur ^ 1);      // the other buffer was last read before the previous barrier
+        // ---- phase 1
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                Frag<T> a;
+                frag_row<T>(a, Kt, kt * 16 + i, sub, g);
+                mma16(s[kt], a, qf[sub]);                // D[key 4g+r][query i]
+                frag_row<T>(a, Vt, kt * 16 + i, sub, g);
+                mma16(dp[kt], a, dof[sub]);
+            }
+        }
+        const unsigned rowb = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb * KBLK + 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float pd[4], dsv[4];
+            bool keep[4] = {true, true, true, true};
+            if (p.drop_thresh) {
+                polus_keep2(p.drop_seed, rowb + kt * 16, p.drop_thresh, keep[0], keep[1]);
+                polus_keep2(p.drop_seed, rowb + kt * 16 + 2, p.drop_thresh, keep[2], keep[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale2, kbc[kb * KBLK + kt * 16 + 4 * g + r]) - lse2);
+                const float pk = keep[r] ? pr * p.drop_inv : 0.f;             // dropped P: what multiplied V forward
+                const float dpe = keep[r] ? dp[kt][r] * p.drop_inv : 0.f;
+                pd[r] = pk;
+                dsv[r] = pr * (dpe - dl) * p.scale;
+                s[kt][r] = dsv[r];
+            }
+            store4<T>(reinterpret_cast<T*>(Ps + q * RSS) + kt * 16 + 4 * g, pd);
+            store4<T>(reinterpret_cast<T*>(Ds + q * RSS) + kt * 16 + 4 * g, dsv);
+        }
+        {
+            Frag<T> dsb;
+            frag_from_acc(dsb, s[0], s[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Frag<T> ka;
+                frag_tr(ka, Kt, 0, dt * 16, i, g);
+                mma16(dq[dt], ka, dsb);                  // D[d][query]
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: this block's dK^T / dV^T tiles, over all queries
+#pragma unroll
+        for (int e = 0; e < TPW; ++e) {
+            const int t = wid * TPW + e;
+            const int type = t >> 3, dt = (t >> 1) & 3, ktile = t & 1;
+            const unsigned char* At = type ? Oc : Qc;
+            const unsigned char* Bt = type ? Ps : Ds;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qs = 0; qs < S / 32; ++qs) {
+                Frag<T> a, bb;
+                frag_tr(a, At, qs * 32, dt * 16, i, g);                  // rows d, k = query
+                frag_tr_rs(bb, Bt, RSS, qs * 32, ktile * 16, i, g);      // k = query (same order), columns = key
+                mma16(acc, a, bb);                                        // D[d 4g+r][key i]
+            }
+            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+            store4<T>(dqkv + (long)(kb * KBLK + ktile * 16 + i) * ld + (type ? 2 * H : H) + h * D + dt * 16 + 4 * g, v);
+        }
+        __syncthreads();
+    }
+    store_acc_T<T>(dqkv, ld, q, h * D, dq, 1.0f, g, true);
+}
+
 int check_common(const char* who, int dtype, int B, int S, int A, int hd) {
     POLUS_REQUIRE(dtype == POLUS_F32 || dtype == POLUS_BF16, "%s: bad dtype %d", who, dtype);
     POLUS_REQUIRE(hd == D, "%s: head_dim must be 64 (got %d)", who, hd);
@@ -454,6 +612,17 @@ int launch_wide_nw(const AttnArgs& a, hipStream_t st) {
     }
     dim3 grid((a.S + QB - 1) / QB, a.A, a.B);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);
+    return POLUS_OK;
+}
+template <int NW>
+int launch_fused(const AttnArgs& a, int n_heads, int B, size_t lds, hipStream_t st) {
+    auto kern = attn_bwd_fused_kernel<NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_heads, B), dim3(64 * NW), lds, st, a);
     return POLUS_OK;
 }
 template <int WHICH>
@@ -508,6 +677,15 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
     a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p); a.dyn = polus_dyn();
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((S + BLK - 1) / BLK, n_heads, B);
+    if (dtype == POLUS_BF16 && polus_cfg().attn_fused && (S == 64 || S == 128 || S == 256)) {
+        // one pass, one workgroup per (batch, head)
+        const size_t lds = 2 * (size_t)S * TileCfg<bf16_t>::RS + 4 * (size_t)KBLK * TileCfg<bf16_t>::RS + 2 * (size_t)S * RSS + (size_t)S * 4;
+        int rc2 = S == 256 ? launch_fused<16>(a, n_heads, B, lds, st) : S == 128 ? launch_fused<8>(a, n_heads, B, lds, st)
+                                                                                   : launch_fused<4>(a, n_heads, B, lds, st);
+        if (rc2 != POLUS_OK) return rc2;
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(fused)");
+        return POLUS_OK;
+    }
     if (dtype == POLUS_BF16) {
         { int rc2 = launch_wide<1>(dtype, a, st); if (rc2 != POLUS_OK) return rc2; }
         POLUS_CHECK_LAUNCH("polus_attention_bwd(dq)");

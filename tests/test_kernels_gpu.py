@@ -182,6 +182,37 @@ def test_attention_fwd_bwd(ops, dtype, B, S, A):
         assert_close(out[..., sl], dqkv_ref[..., sl], 1e-4 if dtype == torch.float32 else 3e-2, nm)
 
 
+@pytest.mark.parametrize("S,A,drop", [(64, 2, 0.0), (128, 3, 0.2), (256, 12, 0.1)])
+def test_attention_backward_one_pass_equals_two_kernel_form(ops, S, A, drop):
+    """The one-pass backward (one workgroup per (batch, head), every score evaluated once; bf16, S in {64, 128,
+    256}) against the two-kernel form on the same inputs, masks and dropout seed: same dropped probabilities and
+    dS in bf16, different summation order only."""
+    B, H = 3, A * 64
+    qkv, mask, dctx = _attn_case(B, S, A, seed=S + A)
+    dt = torch.bfloat16
+    qkv_t, mask_t, dctx_t = dev(qkv.reshape(B * S, 3 * H), dt), dev(mask), dev(dctx.reshape(B * S, H), dt)
+    ctx = torch.empty((B * S, H), dtype=dt, device="cuda")
+    lse = torch.empty((B, A, S), dtype=torch.float32, device="cuda")
+    ops.attention_fwd(qkv_t, mask_t, ctx, lse, B, S, A, drop_p=drop, seed=77)
+    outs = []
+    for fused in (1, 0):
+        ops.set_env("POLUS_ATTN_FUSED", fused)
+        try:
+            d = torch.full((B * S, 3 * H), float("nan"), dtype=dt, device="cuda")
+            ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d, B, S, A, drop_p=drop, seed=77)
+            outs.append(host(d).reshape(B, S, 3 * H))
+        finally:
+            ops.set_env("POLUS_ATTN_FUSED")
+    for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert_close(outs[0][..., sl], outs[1][..., sl], 1.5e-2, nm)
+    # run-to-run bitwise identical
+    d2 = torch.empty((B * S, 3 * H), dtype=dt, device="cuda")
+    ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d2, B, S, A, drop_p=drop, seed=77)
+    d3 = torch.empty_like(d2)
+    ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d3, B, S, A, drop_p=drop, seed=77)
+    assert torch.equal(d2, d3)
+
+
 def test_attention_no_mask_and_all_masked_row(ops):
     B, S, A = 2, 64, 1
     qkv, mask, _ = _attn_case(B, S, A, 9, full_mask=True)

@@ -15,4 +15,7 @@ dqkv = torch.empty_like(qkv)
 for p in (0.0, 0.1):
     tf = bench(lambda: ops.attention_fwd(qkv, mask, ctx, lse, B, S, A, drop_p=p, seed=5), 20)
     tb = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
-    print(f"drop_p={p}: fwd {tf*1e6:.1f} us   bwd (delta+dq+dkv) {tb*1e6:.1f} us", flush=True)
+    ops.set_env("POLUS_ATTN_FUSED", 0)
+    t2 = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
+    ops.set_env("POLUS_ATTN_FUSED")
+    print(f"drop_p={p}: fwd {tf*1e6:.1f} us   bwd one pass {tb*1e6:.1f} us   bwd two kernels (dq + dkv) {t2*1e6:.1f} us", flush=True)
