@@ -1,0 +1,4 @@
+"""polus.optimizers -> polus_amd.optimizers (re-export; no counterpart module in the reference: the Keras / HF objects it stood for came from TensorFlow)."""
+from polus_amd import optimizers as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})

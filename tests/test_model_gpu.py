@@ -15,7 +15,7 @@ import torch
 from oracle import bert as ob
 from oracle import losses as ol
 from oracle import optim as oo
-from tests.util import assert_close, dev, host, relerr
+from tests.util import assert_close, assert_close_elem, dev, host, relerr
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -72,6 +72,12 @@ def test_forward_backward_matches_golden(case, mode):
     og = ob.token_classifier_bwd(params, ocfg, head_w, cache)
     for k, ref in og.items():
         assert_close(got[k], ref, tol["grad"], f"grad {k}")
+        # per element, not per tensor: |a - r| <= rtol |r| + floor * rms(r) (rms over the touched entries), so that the
+        # small-magnitude entries are not hidden behind the tensor's largest one
+        if mode == "f32":
+            assert_close_elem(got[k], ref, 5e-4, 5e-4, f"grad {k} (per element)")
+        else:
+            assert_close_elem(got[k], ref, 0.1, 0.2, f"grad {k} (per element)")
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
