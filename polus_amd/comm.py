@@ -118,11 +118,20 @@ class _NativePlane:
             ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
         self.lib = _lib.load()
         self.check = _lib.check
-        uid = (ctypes.c_ubyte * 128)()
+        # Every rank reaches every control-plane collective below whatever failed locally: a rank that raised
+        # early would leave the others blocked in a broadcast or inside ncclCommInitRank.
+        uid, err = (ctypes.c_ubyte * 128)(), None
         if rk == 0:
-            self.check(self.lib.polus_comm_unique_id(uid), "polus_comm_unique_id")
-        box = [bytes(uid)]
+            try:
+                self.check(self.lib.polus_comm_unique_id(uid), "polus_comm_unique_id")
+            except Exception as e:      # noqa: BLE001
+                err = e
+        box = [bytes(uid) if err is None else None]
         dist.broadcast_object_list(box, src=0)            # control plane (gloo)
+        ready = [None] * world
+        dist.all_gather_object(ready, box[0] is not None)
+        if not all(ready):
+            raise RuntimeError(f"polus_comm_unique_id failed on rank 0: {err}")
         uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
         self.comm = ctypes.c_void_p()
         self.check(self.lib.polus_comm_init(ctypes.byref(self.comm), rk, world, uid), "polus_comm_init")

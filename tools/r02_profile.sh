@@ -1,5 +1,6 @@
 # Round-2 measurement set (run on the GPU box from the repo root): bench line, per-kernel stats, HBM traffic.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/r02_stats gpurun_out/r02_stats_ov gpurun_out/r02_pmc_fetch gpurun_out/r02_pmc_write
 python3 bench.py > gpurun_out/r02_bench_line.json 2> gpurun_out/r02_bench.err || exit 1
 POLUS_OVERLAP_DW=0 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg --no-loss100 > gpurun_out/r02_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_stats_ov -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg --no-loss100 > gpurun_out/r02_stats_ov.log 2>&1 || exit 1
