@@ -16,7 +16,7 @@ T = 16384
 dt, dev = torch.bfloat16, "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda r, c: (torch.rand(r, c, device=dev, generator=g) * 2 - 1).to(dt)
-print(f"{'shape':22s} " + " ".join(f"{n:>12s}" for n in ["full", "noDMA", "noMFMA", "noDMA+MFMA", "noRead", "noDMA+Read", "noMFMA+Read", "barriers", "R-prio"]))
+print(f"{'shape':22s} " + " ".join(f"{n:>12s}" for n in ["full", "noDMA", "noMFMA", "noDMA+MFMA", "noRead", "noDMA+Read", "noMFMA+Read", "barriers", "M-prio"]))
 for tn, N, K in [(256, 3072, 768), (256, 768, 3072), (192, 768, 3072), (192, 2304, 768), (192, 768, 768)]:
     a, b = rnd(T, K), rnd(N, K) * 0.05
     c = torch.empty(T, N, dtype=dt, device=dev)
