@@ -94,6 +94,56 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const T* __restrict_
     }
 }
 
+// ---- bf16, H % 256 == 0: a HALF-wave per row, 16-byte accesses.  Lane (half = lane >> 5, hl = lane & 31) owns
+// columns 8 (hl + 32 c) .. +7 of row 2 w + half: one wave-instruction moves 2 x 512 contiguous bytes (two rows) at
+// 16 B per lane instead of 512 B at 8 B per lane -- 8-byte accesses run at 0.54-0.70 of the 16-byte rate.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int NC>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_hw_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    float gv[NC][8], bv[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = (hl + 32 * c) * 8;
+        load4<float>(gamma + col, *reinterpret_cast<float(*)[4]>(&gv[c][0])); load4<float>(gamma + col + 4, *reinterpret_cast<float(*)[4]>(&gv[c][4]));
+        load4<float>(beta + col, *reinterpret_cast<float(*)[4]>(&bv[c][0])); load4<float>(beta + col + 4, *reinterpret_cast<float(*)[4]>(&bv[c][4]));
+    }
+    const float invH = 1.0f / (float)H;
+    for (int row = (blockIdx.x * WAVES + wid) * 2 + half; row < rows; row += gridDim.x * WAVES * 2) {
+        float v[NC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bf16x8v t = *reinterpret_cast<const bf16x8v*>(x + (long)row * H + (hl + 32 * c) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
+        }
+        const float mu = half_sum(s) * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mu; q += d * d; }
+        const float rs = 1.0f / sqrtf(half_sum(q) * invH + eps);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            bf16x8v o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((v[c][e] - mu) * rs * gv[c][e] + bv[c][e]);
+            *reinterpret_cast<bf16x8v*>(y + (long)row * H + (hl + 32 * c) * 8) = o;
+        }
+        if (hl == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
 struct DropArgs { unsigned thresh, seed; float inv; const PolusDyn* dyn = nullptr; };   // thresh == 0: no dropout; dyn: see common.h
 
 // Shared tail of the LN backward kernels: given x-hat pieces and dy for one row, produce dx
@@ -272,6 +322,103 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
         int which = col / seg, c = col % seg;
         float* out = which == 0 ? out0 : which == 1 ? out1 : out2;
         if (out) out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// LayerNorm backward, half-wave per row (see ln_fwd_hw_kernel).  The two half-waves of a wave own the SAME columns
+// (of two different rows), so the per-feature sums of a wave are the lane-wise sums of its halves (one xor-32
+// shuffle at flush time); the block's waves are then combined through LDS exactly as in the wave-per-row kernel.
+template <int NC>
+__global__ __launch_bounds__(64 * BWD_WAVES) void ln_bwd_hw_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                                    float* __restrict__ partial, int rows, int H, int want_bias,
+                                                                    bf16_t* __restrict__ dxm, DropArgs drop) {
+    if (drop.thresh) drop.seed = polus_eff_seed(drop.seed, drop.dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
+    float gv[NC][8], adg[NC][8], adb[NC][8], abias[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = (hl + 32 * c) * 8;
+        load4<float>(gamma + col, *reinterpret_cast<float(*)[4]>(&gv[c][0])); load4<float>(gamma + col + 4, *reinterpret_cast<float(*)[4]>(&gv[c][4]));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) adg[c][e] = adb[c][e] = abias[c][e] = 0.f;
+    }
+    const float invH = 1.0f / (float)H;
+    for (int row = (blockIdx.x * BWD_WAVES + wid) * 2 + half; row < rows; row += gridDim.x * BWD_WAVES * 2) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NC][8], dxh[NC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const long off = (long)row * H + (hl + 32 * c) * 8;
+            const bf16x8v tx = *reinterpret_cast<const bf16x8v*>(x + off);
+            const bf16x8v td = *reinterpret_cast<const bf16x8v*>(dy + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)td[e];
+                xh[c][e] = ((float)tx[e] - mu) * rs;
+                dxh[c][e] = d * gv[c][e];
+                s1 += dxh[c][e];
+                s2 += dxh[c][e] * xh[c][e];
+                adg[c][e] += d * xh[c][e];
+                adb[c][e] += d;
+            }
+        }
+        s1 = half_sum(s1) * invH;
+        s2 = half_sum(s2) * invH;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = (hl + 32 * c) * 8;
+            float o[8], om[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { o[e] = (dxh[c][e] - s1 - xh[c][e] * s2) * rs; om[e] = o[e]; }
+            if (drop.thresh) polus_dropout_run<8>(om, drop.seed, (unsigned)row * (unsigned)H + col, drop.thresh, drop.inv, true);
+            if (want_bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) abias[c][e] += om[e];
+            }
+            bf16x8v t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (bf16_t)o[e];
+            *reinterpret_cast<bf16x8v*>(dx + (long)row * H + col) = t;
+            if (dxm) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (bf16_t)om[e];
+                *reinterpret_cast<bf16x8v*>(dxm + (long)row * H + col) = t;
+            }
+        }
+    }
+    // the wave's sums = its two halves, lane-wise; then the block's waves through LDS in fixed order
+    float* mine = lds + (long)wid * 3 * H;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = (hl + 32 * c) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            adg[c][e] += __shfl_xor(adg[c][e], 32, 64);
+            adb[c][e] += __shfl_xor(adb[c][e], 32, 64);
+            abias[c][e] += __shfl_xor(abias[c][e], 32, 64);
+        }
+        if (half == 0) {
+            *reinterpret_cast<float4*>(mine + col) = make_float4(adg[c][0], adg[c][1], adg[c][2], adg[c][3]);
+            *reinterpret_cast<float4*>(mine + col + 4) = make_float4(adg[c][4], adg[c][5], adg[c][6], adg[c][7]);
+            *reinterpret_cast<float4*>(mine + H + col) = make_float4(adb[c][0], adb[c][1], adb[c][2], adb[c][3]);
+            *reinterpret_cast<float4*>(mine + H + col + 4) = make_float4(adb[c][4], adb[c][5], adb[c][6], adb[c][7]);
+            *reinterpret_cast<float4*>(mine + 2 * H + col) = make_float4(abias[c][0], abias[c][1], abias[c][2], abias[c][3]);
+            *reinterpret_cast<float4*>(mine + 2 * H + col + 4) = make_float4(abias[c][4], abias[c][5], abias[c][6], abias[c][7]);
+        }
+    }
+    __syncthreads();
+    float* dst = partial + (long)blockIdx.x * 3 * H;
+    const int n = (want_bias ? 3 : 2) * H;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        float t = lds[idx];
+#pragma unroll
+        for (int w = 1; w < BWD_WAVES; ++w) t += lds[(long)w * 3 * H + idx];
+        dst[idx] = t;
     }
 }
 
@@ -511,7 +658,14 @@ extern "C" int polus_layernorm_fwd(int dtype, const void* x, const float* gamma,
     hipStream_t st = static_cast<hipStream_t>(stream);
     int blocks = (rows + WAVES - 1) / WAVES;
     if (blocks > 4096) blocks = 4096;
-    if (dtype == POLUS_BF16)
+    if (dtype == POLUS_BF16 && H % 256 == 0 && H <= 1024 && rows % 2 == 0 && polus_cfg().ln_halfwave) {
+        int hb = (rows / 2 + WAVES - 1) / WAVES;
+        if (hb > 4096) hb = 4096;
+        if (H == 256) hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        else if (H == 512) hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        else if (H == 768) hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        else hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+    } else if (dtype == POLUS_BF16)
         POLUS_NC_DISPATCH(H, bf16_t, ln_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
     else if (dtype == POLUS_F32)
         POLUS_NC_DISPATCH(H, float, ln_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, H, eps);
@@ -539,7 +693,11 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
     float* partial = static_cast<float*>(workspace);
     size_t lds = (size_t)BWD_WAVES * 3 * (size_t)H * sizeof(float);
     int wb = dbias ? 1 : 0;
-    if (dtype == POLUS_BF16)
+    if (dtype == POLUS_BF16 && H % 256 == 0 && H <= 1024 && rows % 2 == 0 && polus_cfg().ln_halfwave && polus_aligned16(dx_masked)) {
+#define POLUS_LN_BWD_HW(NCV) hipLaunchKernelGGL(ln_bwd_hw_kernel<NCV>, dim3(blocks), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb, (bf16_t*)dx_masked, drop)
+        if (H == 256) POLUS_LN_BWD_HW(1); else if (H == 512) POLUS_LN_BWD_HW(2); else if (H == 768) POLUS_LN_BWD_HW(3); else POLUS_LN_BWD_HW(4);
+#undef POLUS_LN_BWD_HW
+    } else if (dtype == POLUS_BF16)
         POLUS_NC_DISPATCH(H, bf16_t, ln_bwd_kernel, dim3(blocks), dim3(64 * BWD_WAVES), lds, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, H, wb, (bf16_t*)dx_masked, drop);
     else if (dtype == POLUS_F32)
         POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(64 * BWD_WAVES), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb, (float*)dx_masked, drop);

@@ -30,6 +30,7 @@ static void read_cfg() {
     g_cfg.attn_waves = env_int("POLUS_ATTN_WAVES", 0);
     g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
     g_cfg.attn_fused = env_int("POLUS_ATTN_FUSED", 1);
+    g_cfg.ln_halfwave = env_int("POLUS_LN_HALFWAVE", 1);
     g_cfg_ready = true;
 }
 const PolusCfg& polus_cfg() {

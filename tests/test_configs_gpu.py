@@ -208,11 +208,16 @@ def test_c4_bert_large_dual_encoder_s512():
     q = {"input_ids": torch.from_numpy(qi).cuda(), "attention_mask": torch.from_numpy(qm).cuda()}
     d = {"input_ids": torch.from_numpy(di).cuda(), "attention_mask": torch.from_numpy(dm).cuda()}
     ref_cls = ob.bert_fwd(params, ocfg, qi[:1], qm[:1])[1]
-    grads, losses = {}, {}
+    grads, losses, rel_hidden = {}, {}, {}
     for mode in ("f32", "bf16"):
         enc = build(ocfg, params, None, None, mode, num_labels=None)
         cls = host(enc(**{k: v[:1] for k, v in q.items()}, training=False).pooler_output)
         assert_close(cls, ref_cls, 1e-4 if mode == "f32" else 5e-2, f"[CLS] of query 0 ({mode})")
+        hid = enc(**q, training=False).last_hidden_state.float()
+        if mode == "f32":
+            hid32 = hid.clone()
+        rel_hidden[mode] = float((hid - hid32).norm() / hid32.norm())
+        del hid
         model = DualEncoder(enc, projection_dim=E, compute_dtype=mode)
         before = enc.arena.params.clone()
         trainer = EfficientDenseRetrievalTrainer(model, InBatchDotScores(), optimizer=Adam(1e-3), loss=ContrastiveLoss())
@@ -223,7 +228,12 @@ def test_c4_bert_large_dual_encoder_s512():
         grads[mode] = {v.name: host(v.grad) for v in model.trainable_weights}
         del trainer, model, enc
         torch.cuda.empty_cache()
-    assert abs(losses["f32"] - losses["bf16"]) < 5e-2 * max(1.0, abs(losses["f32"])), losses
+    # The bf16 engine's encoder output carries 1.2e-2 relative rounding noise after 24 layers whichever LayerNorm
+    # kernel runs (tools/debug/c4_encoder_err.py: wave-per-row 1.23e-2, half-wave 1.23e-2, one against the other
+    # 1.16e-2), and the 8 x 8 in-batch loss built on it sat 0.02 .. 0.17 from the f32 loss over three input seeds
+    # x two kernels (tools/debug/c4_loss.py).  The stable quantity is bounded tightly, the loss at 10 %.
+    assert rel_hidden["bf16"] < 2e-2, rel_hidden
+    assert abs(losses["f32"] - losses["bf16"]) < 0.1 * max(1.0, abs(losses["f32"])), losses
     for k, g32 in grads["f32"].items():
         if g32.size >= 256:
             assert cosine(grads["bf16"][k], g32) > 0.95, (k, cosine(grads["bf16"][k], g32))

@@ -264,6 +264,54 @@ def test_layernorm(ops, dtype, rows, H):
     assert_close(host(dg), 2 * dg_ref, 1e-4, "dgamma accumulate")
 
 
+# y = xhat * g + b cancels to ~1e-6 in a few elements; there the two kernels' f32 values (which differ by an f32
+# eps of the O(1) terms, 3.7e-8 at most observed) straddle many bf16 ulps of the tiny result.  Two f32 eps of 1.0.
+LN_F32_FLOOR = 2.5e-7
+
+
+@pytest.mark.parametrize("rows,H", [(4096, 1024), (4096, 768), (4098, 512), (16, 256)])
+def test_layernorm_halfwave_vs_wave_per_row(ops, rows, H):
+    """The half-wave-per-row bf16 kernels (norm.hip, 16-byte accesses) against the wave-per-row ones on the same
+    input: forward and backward outputs may differ only where the different summation order moved a value across a
+    bf16 rounding boundary (one ulp, a few elements per million), and both sit equally far from the oracle."""
+    r = rng(rows * 3 + H)
+    x = r.standard_normal((rows, H)) * 2 + 0.5
+    g, b = 1 + 0.1 * r.standard_normal(H), 0.1 * r.standard_normal(H)
+    dy = r.standard_normal((rows, H))
+    dt = torch.bfloat16
+    xr, dyr = rounded(x, dt), rounded(dy, dt)
+    g64, b64 = g.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    y_ref, mean_ref, rstd_ref = ob.layer_norm_fwd(xr, g64, b64, 1e-12)
+    dx_ref, dg_ref, db_ref = ob.layer_norm_bwd(dyr, xr, g64, mean_ref, rstd_ref)
+    x_t, dy_t, g_t, b_t = dev(x, dt), dev(dy, dt), dev(g, torch.float32), dev(b, torch.float32)
+    got = {}
+    try:
+        for hw in (0, 1):
+            ops.set_env("POLUS_LN_HALFWAVE", hw)
+            y = torch.full_like(x_t, float("nan"))
+            mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+            ops.layernorm_fwd(x_t, g_t, b_t, y, mean, rstd, 1e-12)
+            dx = torch.full_like(x_t, float("nan"))
+            dg, db, dbias = (torch.full((H,), float("nan"), device="cuda") for _ in range(3))
+            ops.layernorm_bwd(dy_t, x_t, g_t, mean, rstd, dx, dg, db, dbias)
+            assert_close(host(y), y_ref, TOL[dt], f"y (halfwave={hw})")
+            assert_close(host(dx), dx_ref, TOL[dt], f"dx (halfwave={hw})")
+            assert_close(host(mean), mean_ref, 1e-5, "mean"); assert_close(host(rstd), rstd_ref, 1e-5, "rstd")
+            assert_close(host(dg), dg_ref, 1e-4, "dgamma"); assert_close(host(db), db_ref, 1e-4, "dbeta")
+            got[hw] = (host(y), host(dx))
+    finally:
+        ops.set_env("POLUS_LN_HALFWAVE")
+    for name, a, c, ref in (("y", got[0][0], got[1][0], y_ref), ("dx", got[0][1], got[1][1], dx_ref)):
+        differ = a != c
+        assert differ.mean() < 1e-4, (name, differ.mean())
+        if differ.any():   # one bf16 ulp = 2^-7 relative at most
+            d, mag = np.abs(a - c)[differ], np.abs(a)[differ]
+            bad = d > mag * 2.0 ** -7 + LN_F32_FLOOR
+            assert not bad.any(), (name, list(zip(a[differ][bad][:8], c[differ][bad][:8], ref[differ][bad][:8])))
+        ea, ec = np.sqrt(((a - ref) ** 2).mean()), np.sqrt(((c - ref) ** 2).mean())
+        assert abs(ea - ec) < 1e-2 * ea, (name, ea, ec)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("deterministic", [False, True])
 def test_embeddings(ops, dtype, deterministic):
