@@ -354,6 +354,138 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue of one wave with TWO whole-m-tile staging buffers (gemm_pp.hip, whose operand stages are dead by then:
+// 2 x 16 rows x RS bytes per wave).  epilogue_wave above pays two LDS round trips per half m-tile -- its next
+// staging write has to wait for the reads of the rows it overwrites to have been *consumed* -- which at two waves
+// per SIMD is most of its time (tools/pp_epi_probe.py: 5.6 us per 256 x 256 tile for 433 instructions).  Here the
+// reads of m-tile mt are followed at once by the staging writes of m-tile mt + 2 into the same buffer: LDS executes
+// the operations of one wave in order, so the write-after-read needs no wait, and the math of mt then runs with
+// every LDS access of the next two m-tiles already in flight.  Same arithmetic, same operation order and the same
+// global accesses as epilogue_wave<..., AGPR = false>: results are bit-identical to it.
+template <int WN> struct EpiDbCfg {
+    static constexpr int RS = EpiCfg<WN>::RS;
+    static constexpr int BUF = 16 * RS;
+    static constexpr int BYTES = 2 * BUF;
+};
+template <typename TC, int WN, bool DROP, int MODE>
+__device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)[8][WN / 16], int mb, int nb,
+                                                 int lane, unsigned char* lds) {
+    typedef bf16_t T;
+    constexpr int NT = WN / 16, RS = EpiDbCfg<WN>::RS, BUF = EpiDbCfg<WN>::BUF, PASSES = EpiCfg<WN>::PASSES, CPR = 2 * NT;
+    constexpr int SLOTS = EpiCfg<WN>::SLOTS;
+    const int i = lane & 15, g = lane >> 4;
+    const bool interior = p.epi_vec16 && (mb + 128 <= p.M) && (nb + WN <= p.N);
+    if (!interior) {
+#pragma clang loop unroll(full)
+        for (int mt = 0; mt < 8; ++mt)
+#pragma clang loop unroll(full)
+            for (int nt = 0; nt < NT; ++nt)
+                epilogue_tile<T, TC, DROP>(p, acc_take<false>(acc[mt][nt]), mb + mt * 16 + i, nb + nt * 16 + 4 * g, 0);
+        return;
+    }
+    constexpr bool act_fwd = MODE == 1, act_bwd = MODE == 3, has_resid = MODE == 2;
+    const T* resid = static_cast<const T*>(p.resid);
+    T* aux = static_cast<T*>(p.aux);
+    TC* C = static_cast<TC*>(p.C);
+    int prow[PASSES], pcol[PASSES];
+    float bv[PASSES][8];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int slot = (ps * 64 + lane) % SLOTS;     // lanes past the last slot repeat an earlier one (see epilogue_wave)
+        prow[ps] = slot / CPR;
+        pcol[ps] = 8 * (slot % CPR);
+        if (p.bias) {
+            load4<float>(p.bias + nb + pcol[ps], *reinterpret_cast<float(*)[4]>(&bv[ps][0]));
+            load4<float>(p.bias + nb + pcol[ps] + 4, *reinterpret_cast<float(*)[4]>(&bv[ps][4]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bv[ps][r] = 0.f;
+        }
+    }
+    constexpr int DEPTH = 4, NBUF = DEPTH + 1;         // residual / aux rows fetched DEPTH m-tiles ahead (see epilogue_wave)
+    bf16x8_t pre[NBUF][2][PASSES];
+    auto fetch = [&](int mt, bf16x8_t (&dst)[2][PASSES]) {
+        const T* base = has_resid ? resid : static_cast<const T*>(aux);
+        const long ld = has_resid ? p.ldr : p.ldaux;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps)
+                dst[h][ps] = *reinterpret_cast<const bf16x8_t*>(base + (long)(mb + mt * 16 + h * 8 + prow[ps]) * ld + nb + pcol[ps]);
+    };
+    auto stage = [&](int mt) {                         // lane (i, g): row i, columns nt * 16 + 4 g .. of every n-tile
+        unsigned char* wrow = lds + (mt & 1) * BUF + i * RS;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            *reinterpret_cast<f32x4*>(wrow + (nt * 16 + 4 * g) * 4) = acc_take<false>(acc[mt][nt]);
+    };
+    if (has_resid || act_bwd) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) fetch(d, pre[d % NBUF]);
+    }
+    stage(0);
+    stage(1);
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < 8; ++mt) {
+        f32x4 lo[2][PASSES], hi[2][PASSES];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const unsigned char* src = lds + (mt & 1) * BUF + (h * 8 + prow[ps]) * RS + pcol[ps] * 4;
+                lo[h][ps] = *reinterpret_cast<const f32x4*>(src);
+                hi[h][ps] = *reinterpret_cast<const f32x4*>(src + 16);
+            }
+        if (mt + 2 < 8) stage(mt + 2);                 // behind the reads above in the wave's LDS queue: no wait needed
+        if ((has_resid || act_bwd) && mt + DEPTH < 8) fetch(mt + DEPTH, pre[(mt + DEPTH) % NBUF]);
+#pragma clang loop unroll(full)
+        for (int h = 0; h < 2; ++h) {
+#pragma clang loop unroll(full)
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const long m = mb + mt * 16 + h * 8 + prow[ps];
+                const int ncol = nb + pcol[ps];
+                float v[8] = {lo[h][ps][0], lo[h][ps][1], lo[h][ps][2], lo[h][ps][3], hi[h][ps][0], hi[h][ps][1], hi[h][ps][2], hi[h][ps][3]};
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = v[r] * p.alpha + bv[ps][r];
+                if (act_fwd) {
+                    if (aux) {
+                        bf16x8_t tt;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
+                        __builtin_nontemporal_store(tt, reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol));
+                    }
+                    apply_act_n<8, true>(p.act, v);
+                }
+                if (act_bwd) {
+                    float u[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) u[r] = (float)pre[mt % NBUF][h][ps][r];
+                    apply_act_grad_n<8, true>(p.act, v, u);
+                }
+                if (DROP) {
+                    const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
+                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 1) == 0);
+                }
+                if (has_resid) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)pre[mt % NBUF][h][ps][r];
+                }
+                if (sizeof(TC) == 4) {
+                    float* dst = reinterpret_cast<float*>(C) + m * p.ldc + ncol;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    bf16x8_t tt;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
+                    *reinterpret_cast<bf16x8_t*>(reinterpret_cast<T*>(C) + m * p.ldc + ncol) = tt;
+                }
+            }
+        }
+    }
+}
+
 
 // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
 // contiguous run of tiles so that neighbours reuse the same A row panel.

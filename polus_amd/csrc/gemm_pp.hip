@@ -59,10 +59,12 @@ template <int NT> struct PPCfg {
     static constexpr int WN = 16 * NT, TN = 4 * WN, NB = TN / 64;
     static constexpr int STAGE = A_REGION + TN * 128;
     static constexpr int SMEM = 2 * STAGE;
+    static_assert(8 * ((EpiDbCfg<WN>::BYTES + 255) / 256 * 256) <= SMEM, "the C staging buffers of the 8 waves reuse the operand stages");
 };
 
 // ABL (diagnostics, POLUS_GEMM_ABLATE): bit0 = no LDS-DMA inside the K loop, bit1 = no MFMA, bit2 = no fragment reads,
-// bit3 = raised priority for the M sections instead of the R sections
+// bit3 = raised priority for the M sections instead of the R sections, bit4 = no epilogue,
+// bit6 = staggered start of half the first-round workgroups (bits 4 and 6: 256 x 256 tile only)
 template <int NT, bool DROP, int MODE, int ABL = 0>
 __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     typedef PPCfg<NT> C;
@@ -74,6 +76,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     const int i = lane & 15, g = lane >> 4;
     const int wm = wid >> 2, wn = wid & 3;
 
+    if (ABL & 64) {
+        // diagnostics: every other first-round workgroup of an XCD starts (p.ablate >> 8) x 10 ns late, so that from
+        // then on half of the CUs reach their epilogues while the other half are inside their K loops
+        if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+            const unsigned long t0 = wall_clock64(), dt = (unsigned long)(p.ablate >> 8);
+            while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     const int tiles_n = (p.N + TN - 1) / TN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
@@ -203,8 +213,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
 
     if (wm == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's last barrier (b)
     // every wave is done with the operand stages and no DMA is in flight: LDS now stages C
-    epilogue_wave<bf16_t, WN, DROP, MODE, false>(p, acc, m0 + wm * 128, n0 + wn * WN, lane,
-                                                 smem + wid * ((EpiCfg<WN>::BYTES + 255) / 256 * 256));
+    if (ABL & 16) {                                        // diagnostics: no epilogue (the accumulators stay live)
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) asm volatile("" :: "v"(acc[a][b]));
+        return;
+    }
+    // (two staging buffers per wave: bit-identical to the ring kernel's epilogue_wave, tests/test_kernels_gpu.py)
+    epilogue_wave_db<bf16_t, WN, DROP, MODE>(p, acc, m0 + wm * 128, n0 + wn * WN, lane,
+                                             smem + wid * ((EpiDbCfg<WN>::BYTES + 255) / 256 * 256));
 }
 
 template <int NT, bool DROP, int MODE, int ABL = 0>
@@ -226,7 +244,9 @@ int launch_pp(const GemmArgs& a, hipStream_t st) {
 template <int NT>
 int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
     if (a.ablate && mode == 0) {
-        switch (a.ablate & 15) {
+        switch (a.ablate & 31) {
+            case 16: if constexpr (NT == 4) return launch_pp<NT, false, 0, 16>(a, st); else break;
+            case 23: if constexpr (NT == 4) return launch_pp<NT, false, 0, 23>(a, st); else break;
             case 7: return launch_pp<NT, false, 0, 7>(a, st);
             case 8: return launch_pp<NT, false, 0, 8>(a, st);
             case 1: return launch_pp<NT, false, 0, 1>(a, st);
@@ -236,6 +256,16 @@ int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
             case 5: return launch_pp<NT, false, 0, 5>(a, st);
             case 6: return launch_pp<NT, false, 0, 6>(a, st);
             default: break;
+        }
+    }
+    if constexpr (NT == 4) {
+        if ((a.ablate & 255) == 64) {                      // staggered start (delay in bits 8..), tools/pp_stagger_probe.py
+            switch (mode) {
+                case 0: return launch_pp<NT, false, 0, 64>(a, st);
+                case 1: return launch_pp<NT, false, 1, 64>(a, st);
+                case 3: return launch_pp<NT, false, 3, 64>(a, st);
+                default: break;
+            }
         }
     }
     switch (mode) {
