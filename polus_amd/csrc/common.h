@@ -40,6 +40,7 @@ struct PolusCfg {
     int ablate;            // POLUS_GEMM_ABLATE: diagnostics (bit0 no in-loop DMA, bit1 no MFMA)
     int attn_waves;        // POLUS_ATTN_WAVES: 0 default
     int dw_fused_reduce;   // POLUS_DW_FUSED_REDUCE: 1 (default) one reduce launch per grouped dW
+    int ln_bwd_blocks;     // POLUS_LN_BWD_BLOCKS: cap on LayerNorm-backward workgroups (default 512 = all resident at once, one reduce stage; 1024 = round-1 grid, two stages)
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward for S in {64, 128, 256} (bf16)
 };

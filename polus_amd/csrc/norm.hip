@@ -268,9 +268,10 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
     }
 }
 
-// LayerNorm backward proper runs 4-wave workgroups (up to 1024 of them: shorter tail, cheap
-// flush); its [blocks][3H] partials are reduced in two fixed-order stages.
-constexpr int BWD_WAVES = 4, BWD_MAX_BLOCKS = 1024, FIN_GROUP = 128;
+// LayerNorm backward proper runs 4-wave workgroups.  At ~210 VGPRs two of them fit a CU, so 512 are resident at
+// once: the default cap (POLUS_LN_BWD_BLOCKS).  Their [blocks][3H] partials are reduced in fixed order by one
+// finalize launch; above FIN_SINGLE blocks (the round-1 grid of 1024) in two stages, groups of FIN_GROUP first.
+constexpr int BWD_WAVES = 4, BWD_MAX_BLOCKS = 1024, FIN_GROUP = 128, FIN_SINGLE = 512;
 template <typename T, int NC>
 __global__ __launch_bounds__(64 * BWD_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -489,7 +490,9 @@ int colsum_launch(int dtype, const void* x, long ldx, int rows, int cols, float*
 
 int ln_bwd_blocks(int rows) {
     int b = (rows + BWD_WAVES - 1) / BWD_WAVES;
-    return b > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : (b < 1 ? 1 : b);
+    int cap = polus_cfg().ln_bwd_blocks;
+    cap = cap < 64 ? 64 : (cap > BWD_MAX_BLOCKS ? BWD_MAX_BLOCKS : cap);
+    return b > cap ? cap : (b < 1 ? 1 : b);
 }
 int ln_blocks(int rows) {
     int b = (rows + WAVES - 1) / WAVES;
@@ -704,7 +707,7 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
     else POLUS_FAIL("polus_layernorm_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd");
     int ncols = (wb ? 3 : 2) * H;
-    if (blocks > 2 * FIN_GROUP) {
+    if (blocks > FIN_SINGLE) {
         // two fixed-order stages: [blocks] -> [groups] -> result (a single stage would leave most
         // of the chip idle: ncols/64 workgroups walking 1024 rows each)
         int groups = (blocks + FIN_GROUP - 1) / FIN_GROUP;

@@ -38,8 +38,9 @@ def test_workspace_queries_are_host_only(lib):
     assert lib.polus_gemm_workspace_bytes(768, 768, 1) == 0
     assert lib.polus_gemm_workspace_bytes(768, 768, 4) == 4 * 768 * 768 * 4
     assert lib.polus_attention_bwd_workspace_bytes(2, 128, 12) == 2 * 128 * 12 * 4
-    # 1024 block partials + 8 second-stage group partials, [3H] f32 each
-    assert lib.polus_layernorm_bwd_workspace_bytes(16384, 768) == (1024 + 8) * 3 * 768 * 4
+    # 512 block partials (POLUS_LN_BWD_BLOCKS default: every workgroup resident at once) + room for
+    # ceil(512 / 128) second-stage group partials, [3H] f32 each
+    assert lib.polus_layernorm_bwd_workspace_bytes(16384, 768) == (512 + 4) * 3 * 768 * 4
     assert lib.polus_crf_workspace_bytes(4, 16, 3) >= (4 * 16 * 3 + 4 + 4 * 9) * 4
     assert lib.polus_sqnorm_workspace_bytes(10 ** 8) == 1024 * 4
 
