@@ -400,7 +400,7 @@ class GradBucketReducer:
     def begin(self):
         self._next, self._ready_lo, self._works = 0, self.grads.numel(), []
 
-    def on_ready(self, lo, hi):
+    def on_ready(self, lo, hi, variables=None):
         """Model hook: grads[lo:hi] are final (called in descending arena order)."""
         self._ready_lo = min(self._ready_lo, lo)
         self._launch_ready()

@@ -299,7 +299,7 @@ class PolusModel:
 
     def __init__(self, name=None):
         self._name = name or self.__class__.__name__.lower()
-        self.grad_ready_hook = None   # called as hook(lo, hi) when grads[lo:hi] are final
+        self.grad_ready_hook = None   # called as hook(lo, hi, variables) when the gradients of `variables` (arena window [lo, hi)) are final
         self.deterministic = False
         self.savable_config = {}
 
@@ -332,7 +332,7 @@ class PolusModel:
         if self.grad_ready_hook is not None and variables:
             lo = min(v.offset for v in variables)
             hi = max(v.offset + v.size for v in variables)
-            self.grad_ready_hook(lo, hi)
+            self.grad_ready_hook(lo, hi, variables)
 
 
 def _to_numpy(a):

@@ -16,6 +16,52 @@ from .context import PolusContext, logger
 hvd = comm
 
 
+class _UpdateInBackward:
+    """Single-process steps: the fused optimizer update of a gradient window starts as soon as backward reports the
+    window final (`model.grad_ready_hook`), on its own stream, beside the backward pass of the layers below -- the
+    update is HBM-bound, backward mostly MFMA-bound.  Same kernel, same arithmetic per parameter as the one launch
+    of `optimizer.apply_gradients` after backward (polus/training.py:191): the parameters come out bit-identical
+    (tests/test_boundary_gpu.py).  The transposed shadows of the GEMM weights are re-derived once, at the end; the
+    main stream joins before `train_step` returns."""
+
+    def __init__(self, trainer, arena):
+        import torch
+        self.trainer, self.arena = trainer, arena
+        self.stream = torch.cuda.Stream(device=arena.device)
+        self.fork, self.done = torch.cuda.Event(), torch.cuda.Event()
+        self.vars = sorted(trainer.trainable_weights, key=lambda v: v.offset)
+
+    def begin(self):
+        self.first = True
+        self.left = {id(v): v for v in self.vars}
+
+    def _apply(self, vs):
+        import torch
+        main = torch.cuda.current_stream()
+        self.fork.record(main)               # everything that read these parameters was launched before this point
+        self.stream.wait_event(self.fork)
+        with _lib.stream_scope(self.stream):
+            self.trainer.optimizer.apply_gradients([(v.grad, v) for v in vs], _advance=self.first, _refresh=False)
+        self.first = False
+        for v in vs:
+            del self.left[id(v)]
+
+    def on_ready(self, lo, hi, variables=None):
+        # by identity: a model may report windows of an arena this trainer does not update
+        vs = [v for v in (variables or ()) if id(v) in self.left]
+        if vs:
+            self._apply(vs)
+
+    def finish(self):
+        import torch
+        if self.left:                        # windows backward never reported (a model without the hook calls)
+            self._apply(list(self.left.values()))
+        with _lib.stream_scope(self.stream):
+            self.arena.refresh_transposed()
+            self.done.record(self.stream)
+        torch.cuda.current_stream().wait_event(self.done)
+
+
 class BaseTrainer:
     """polus/training.py:14-338."""
 
@@ -92,6 +138,26 @@ class BaseTrainer:
             m = self._dp_mode_cached = "rs" if ok else "allreduce"
         return m
 
+    def _updater(self):
+        """The in-backward optimizer update (see _UpdateInBackward), when nothing needs all gradients at once: one
+        process, one arena on the GPU swept by the fused Adam, no post_process_grads, no global-norm clipping, no
+        step graph (its eager warm-up steps must take the path that is captured).  POLUS_UPDATE_IN_BACKWARD=0 keeps
+        the single launch after backward."""
+        if getattr(self, "_graphed", None) is not None:
+            return None
+        key = tuple(id(v) for v in self.trainable_weights)
+        u = getattr(self, "_updater_cached", False)
+        if u is False or getattr(self, "_updater_key", None) != key:
+            self._updater_key = key
+            arenas = self._arenas()
+            ok = (os.environ.get("POLUS_UPDATE_IN_BACKWARD", "1") != "0" and len(arenas) == 1 and
+                  hasattr(self.model, "grad_ready_hook") and isinstance(self.optimizer, Adam) and
+                  hasattr(self.optimizer, "grad_scale") and not self.optimizer.global_clipnorm and
+                  self.post_process_grads is None and hasattr(arenas[0], "refresh_transposed") and
+                  arenas[0].grads.is_cuda and all(v.arena is arenas[0] for v in self.trainable_weights))
+            u = self._updater_cached = _UpdateInBackward(self, arenas[0]) if ok else None
+        return u
+
     def _reducer(self, arena):
         r = self._reducers.get(id(arena))
         if r is None:
@@ -145,8 +211,17 @@ class BaseTrainer:
                 r.begin()
                 self.model.grad_ready_hook = r.on_ready
                 reducers = [r]
+        updater = self._updater() if (last and not self.use_horovod) else None
+        if updater is not None:
+            self.optimizer.grad_scale = 1.0 / accum
+            updater.begin()
+            self.model.grad_ready_hook = updater.on_ready
         self.backward_from_loss(accumulate=not first)
         self.step_counter_micro = micro + 1
+        if updater is not None:
+            self.model.grad_ready_hook = None
+            updater.finish()
+            return loss_value
         if not last:
             return loss_value
 

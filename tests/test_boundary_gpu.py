@@ -341,3 +341,47 @@ def test_graphed_step_equals_eager_step_bitwise(mode):
     assert eager == graphed, (eager, graphed)
     assert torch.equal(p_eager, p_graph)
     assert eager[-1] < eager[0]
+
+
+@pytest.mark.parametrize("mode,accum", [("bf16", 1), ("f32", 1), ("bf16", 2)])
+def test_update_in_backward_equals_single_launch_bitwise(mode, accum, monkeypatch):
+    """Single-process steps run the fused AdamW of each gradient window on a side stream as soon as backward
+    reports it final (training._UpdateInBackward).  Same kernel and arithmetic as the one launch after backward
+    (polus/training.py:191): losses, parameters, both Adam slots and the transposed bf16 shadows must come out
+    bit-identical, with dropout on, a warm-up schedule, and under gradient accumulation (last micro-step only)."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import BertConfig, BertModel
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.schedulers import warmup_scheduler
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    g, ocfg, params, hw, hb = load_case("bert_small_b3_s48")
+    steps = 6
+
+    def run(in_backward):
+        monkeypatch.setenv("POLUS_UPDATE_IN_BACKWARD", "1" if in_backward else "0")
+        cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                         ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size,
+                         hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        m = BertModel(cfg, compute_dtype=mode, num_labels=hw.shape[0])
+        m.load_numpy_params(params, hw, hb)
+        m.deterministic = True
+        t = ClassifierTrainer(m, AdamWeightDecay(learning_rate=warmup_scheduler(steps, 1e-3), weight_decay_rate=0.01),
+                              SparseCategoricalCrossentropy(grad_dtype=m.compute_dtype))
+        t.grad_accum_steps = accum
+        losses = []
+        for s in range(steps * accum):
+            ids, mask, tt, labels = synth_batch(ocfg, 3, 48, 4, 700 + s)
+            losses.append(t.train_step({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels))
+        out = [float(l) for l in losses]
+        torch.cuda.synchronize()
+        assert (t._updater() is not None) == in_backward
+        assert t.optimizer.iterations == steps
+        mm, vv = t.optimizer._slots(m.arena)
+        extra = [m.arena.shadow_t.clone()] if getattr(m.arena, "shadow_t", None) is not None else []
+        return out, [m.arena.params.clone(), mm.clone(), vv.clone()] + extra
+    l_ref, s_ref = run(False)
+    l_new, s_new = run(True)
+    assert l_ref == l_new, (l_ref, l_new)
+    for a, b in zip(s_ref, s_new):
+        assert torch.equal(a, b)
