@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 float t4[4] = {s[kt][0], s[kt][1], s[kt][2], s[kt][3]};
-                polus_dropout_run<4>(t4, p.drop_seed, rowb + kt * 16, p.drop_thresh, p.drop_inv, (S & 1) == 0);
+                polus_dropout_run<4>(t4, p.drop_seed, rowb + kt * 16, p.drop_thresh, p.drop_inv, (S & 3) == 0);
                 s[kt] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
             }
         }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
             if (p.drop_thresh) {
                 float t4[4] = {dp[kt][0], dp[kt][1], dp[kt][2], dp[kt][3]};
                 const unsigned idx0 = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb0 + kt * 16 + 4 * g;
-                polus_dropout_run<4>(t4, p.drop_seed, idx0, p.drop_thresh, p.drop_inv, (S & 1) == 0);
+                polus_dropout_run<4>(t4, p.drop_seed, idx0, p.drop_thresh, p.drop_inv, (S & 3) == 0);
                 dp[kt] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
             }
 #pragma unroll
@@ -536,8 +536,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
             float pd[4], dsv[4];
             bool keep[4] = {true, true, true, true};
             if (p.drop_thresh) {
-                polus_keep2(p.drop_seed, rowb + kt * 16, p.drop_thresh, keep[0], keep[1]);
-                polus_keep2(p.drop_seed, rowb + kt * 16 + 2, p.drop_thresh, keep[2], keep[3]);
+                polus_keep4(p.drop_seed, rowb + kt * 16, p.drop_thresh, keep);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

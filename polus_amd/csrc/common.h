@@ -40,7 +40,8 @@ struct PolusCfg {
     int ablate;            // POLUS_GEMM_ABLATE: diagnostics (bit0 no in-loop DMA, bit1 no MFMA)
     int attn_waves;        // POLUS_ATTN_WAVES: 0 default
     int dw_fused_reduce;   // POLUS_DW_FUSED_REDUCE: 1 (default) one reduce launch per grouped dW
-    int ln_bwd_blocks;     // POLUS_LN_BWD_BLOCKS: cap on LayerNorm-backward workgroups (default 512 = all resident at once, one reduce stage; 1024 = round-1 grid, two stages)
+    int ln_bwd_blocks;     // POLUS_LN_BWD_BLOCKS: cap on LayerNorm-backward workgroups (default 512 = all resident at once; 1024 = round-1 grid)
+    int ln_fin_single;     // POLUS_LN_FIN_SINGLE: LayerNorm-backward partials up to this many rows are reduced by one finalize launch, more in two stages (default 512)
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward for S in {64, 128, 256} (bf16)
 };
@@ -194,12 +195,17 @@ template <int N, bool FAST = false> __device__ __forceinline__ void apply_act_gr
 
 // ---------------------------------------------------------------- dropout (counter-based)
 // keep(seed, idx) is a pure function of (seed, element index): forward and backward regenerate
-// the same mask instead of storing it.  One murmur3-finaliser hash serves TWO elements: element
-// idx takes the 16-bit half (idx & 1) of hash(seed, idx >> 1) and is kept when that half is
-// >= thresh = round(p * 65536) (p resolved to 1.5e-5).  The fused epilogues are VALU-bound, and
-// the hash is a third of their work; kernels whose lanes hold an even-aligned run of elements use
-// polus_keep2 (one hash per pair), the rest polus_keep -- same mask either way.  The per-call seed
-// already mixes step / layer / site on the host.
+// the same mask instead of storing it.  One murmur3-finaliser hash serves FOUR elements: with
+// h1 = hash32(seed, idx >> 2) and h2 = xs15(h1 * 0x27D4EB2F), elements 4n .. 4n+3 take the 16-bit
+// fields h1.lo, h1.hi, h2.lo, h2.hi and are kept when their field is >= thresh = round(p * 65536)
+// (p resolved to 1.5e-5).  The fused epilogues and the attention kernels are VALU-bound and the hash's
+// 32-bit multiplies run at quarter rate: four multiplies per four elements instead of six.  The
+// derived fields were checked against the two-field form (tools/debug/hash_eval.py and the battery in
+// tests/test_kernels_gpu.py: keep rate, serial correlation at tensor strides up to 2^28 elements, and the
+// six pairings inside a quad, all within noise); two-round hashes on 24-bit multiplies, which would be
+// cheaper still, were not (correlations of 4-50 sigma at power-of-two lags).
+// Kernels whose lanes hold a 4-aligned run of elements use polus_keep4 (one hash per quad), the rest
+// polus_keep -- same mask either way.  The per-call seed already mixes step / layer / site on the host.
 __device__ __forceinline__ uint32_t polus_hash32(uint32_t seed, uint32_t idx) {
     uint32_t x = idx * 0x9E3779B1u + seed;
     x ^= x >> 16; x *= 0x85EBCA6Bu;
@@ -207,26 +213,34 @@ __device__ __forceinline__ uint32_t polus_hash32(uint32_t seed, uint32_t idx) {
     x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ uint32_t polus_hash32_second(uint32_t h1) {
+    uint32_t y = h1 * 0x27D4EB2Fu;
+    return y ^ (y >> 15);
+}
 __device__ __forceinline__ bool polus_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
-    const uint32_t h = polus_hash32(seed, idx >> 1);
+    const uint32_t h1 = polus_hash32(seed, idx >> 2);
+    const uint32_t h = (idx & 2u) ? polus_hash32_second(h1) : h1;
     return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh;
 }
-// idx_even must be even: masks of elements idx_even and idx_even + 1
-__device__ __forceinline__ void polus_keep2(uint32_t seed, uint32_t idx_even, uint32_t thresh, bool& k0, bool& k1) {
-    const uint32_t h = polus_hash32(seed, idx_even >> 1);
-    k0 = (h & 0xFFFFu) >= thresh;
-    k1 = (h >> 16) >= thresh;
+// idx4 must be a multiple of 4: masks of elements idx4 .. idx4 + 3
+__device__ __forceinline__ void polus_keep4(uint32_t seed, uint32_t idx4, uint32_t thresh, bool (&k)[4]) {
+    const uint32_t h1 = polus_hash32(seed, idx4 >> 2), h2 = polus_hash32_second(h1);
+    k[0] = (h1 & 0xFFFFu) >= thresh;
+    k[1] = (h1 >> 16) >= thresh;
+    k[2] = (h2 & 0xFFFFu) >= thresh;
+    k[3] = (h2 >> 16) >= thresh;
 }
-// v[r] = keep(base + r) ? v[r] * inv : 0 for r < N (N even); `even` says base is even (uniform)
+// v[r] = keep(base + r) ? v[r] * inv : 0 for r < N (N a multiple of 4); `quad` says base is a multiple of 4 (uniform)
 template <int N>
-__device__ __forceinline__ void polus_dropout_run(float (&v)[N], uint32_t seed, uint32_t base, uint32_t thresh, float inv, bool even) {
-    if (even) {
+__device__ __forceinline__ void polus_dropout_run(float (&v)[N], uint32_t seed, uint32_t base, uint32_t thresh, float inv, bool quad) {
+    static_assert(N % 4 == 0, "runs of whole quads");
+    if (quad) {
 #pragma unroll
-        for (int r = 0; r < N; r += 2) {
-            bool k0, k1;
-            polus_keep2(seed, base + r, thresh, k0, k1);
-            v[r] = k0 ? v[r] * inv : 0.f;
-            v[r + 1] = k1 ? v[r + 1] * inv : 0.f;
+        for (int r = 0; r < N; r += 4) {
+            bool k[4];
+            polus_keep4(seed, base + r, thresh, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[r + e] = k[e] ? v[r + e] * inv : 0.f;
         }
     } else {
 #pragma unroll

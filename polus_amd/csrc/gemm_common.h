@@ -182,7 +182,7 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
             }
             if (DROP) {
                 const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
-                polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 1) == 0);
+                polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 3) == 0);
             }
             if (resid) {
 #pragma unroll
@@ -333,7 +333,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
                 }
                 if (DROP) {
                     const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
-                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 1) == 0);
+                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 3) == 0);
                 }
                 if (has_resid) {
 #pragma unroll
@@ -465,7 +465,7 @@ __device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)
                 }
                 if (DROP) {
                     const unsigned base = (unsigned)m * (unsigned)p.N + (unsigned)ncol;
-                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 1) == 0);
+                    polus_dropout_run<8>(v, p.drop_seed, base, p.drop_thresh, p.drop_inv, (p.N & 3) == 0);
                 }
                 if (has_resid) {
 #pragma unroll

@@ -726,6 +726,39 @@ def test_gemm_pingpong_256wide(ops, tn, M, N, K):
         ops.set_env("POLUS_GEMM_PP")
 
 
+def test_dropout_mask_definition_and_statistics(ops):
+    """The dropout mask is the engine's own counter-based generator (one murmur3-finaliser hash per FOUR elements,
+    polus_amd/csrc/common.h).  Pinned here against a numpy restatement at several offsets (aligned and not, and
+    across the 32-bit wrap), and held to the statistics a mask needs -- fixed seeds, so this either passes or not:
+    keep rate, serial correlation at the strides tensors have (neighbouring keys, next query row at S = 256 / 257,
+    next token row at H = 768, next head), and the six pairings of the fields that share one hash."""
+    from tests.util import dropout_keep_np
+    for seed, p, idx0, n in ((123, 0.1, 0, 4099), (0xDEADBEEF, 0.25, 5, 1001), (7, 0.5, 2, 64), (99, 0.1, 0xFFFFFFF0 - 100, 90), (1, 0.9, 1 << 30, 513)):
+        got = host(ops.dropout_mask(seed, p, n, idx0=idx0)).astype(np.uint8)
+        assert np.array_equal(got, dropout_keep_np(seed, p, idx0, n)), (seed, p, idx0)
+    N = 1 << 24
+    for seed in (0x12345678, 0x5BD1E995):
+        k = host(ops.dropout_mask(seed, 0.1, N)).astype(np.float64)
+        q = 1.0 - round(0.1 * 65536) / 65536.0
+        assert abs(k.mean() - q) / np.sqrt(q * (1 - q) / N) < 4.5, ("keep rate", seed, k.mean())
+        kd = k - k.mean()
+        var = float((kd * kd).mean())
+        for lag in (1, 2, 3, 4, 8, 64, 256, 257, 768, 65536, 65536 * 12):
+            z = float(np.dot(kd[:-lag], kd[lag:])) / (N - lag) / var * np.sqrt(N - lag)
+            assert abs(z) < 4.5, ("serial correlation", seed, lag, z)
+        quad = kd.reshape(-1, 4)
+        for a in range(4):
+            for b in range(a + 1, 4):
+                z = float(np.dot(quad[:, a], quad[:, b])) / (N / 4) / var * np.sqrt(N / 4)
+                assert abs(z) < 4.5, ("fields of one hash", seed, a, b, z)
+    # two seeds as the host derives them for neighbouring sites / steps give unrelated masks
+    a = host(ops.dropout_mask(0x3C6EF372, 0.1, 1 << 22)).astype(np.float64)
+    for other in (0x3C6EF373, 0x3C6EF372 ^ 0x9E3779B1, (0x3C6EF372 + 0x85EBCA6B) & 0xFFFFFFFF, (0x3C6EF372 + 9 * 0xC2B2AE35) & 0xFFFFFFFF):
+        b = host(ops.dropout_mask(other, 0.1, 1 << 22)).astype(np.float64)
+        z = float(np.corrcoef(a, b)[0, 1]) * np.sqrt(1 << 22)
+        assert abs(z) < 4.5, ("cross-seed correlation", hex(other), z)
+
+
 def test_gelu_polynomial_epilogue_precision(ops):
     """The bf16 GEMM epilogues evaluate GELU / GELU' by a degree-10 polynomial in x^2 (no erf, no
     exp): through an identity product the error against the exact erf form must stay below a

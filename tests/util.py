@@ -53,3 +53,21 @@ def assert_close_elem(actual, ref, rtol, atol_rms, what=""):
 def cosine(a, b):
     a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def dropout_keep_np(seed, drop_p, idx0, n):
+    """numpy restatement of the engine's counter-based dropout mask (polus_amd/csrc/common.h polus_keep): element idx
+    takes 16-bit field (idx & 3) of the pair (h1, h2), h1 = murmur3 finaliser of (idx >> 2) * 0x9E3779B1 + seed,
+    h2 = xs15(h1 * 0x27D4EB2F); kept when the field is >= round(p * 65536)."""
+    U, M = np.uint64, np.uint64(0xFFFFFFFF)
+    idx = (np.arange(n, dtype=np.uint64) + U(idx0)) & M
+    x = ((idx >> U(2)) * U(0x9E3779B1) + U(int(seed) & 0xFFFFFFFF)) & M
+    x ^= x >> U(16); x = (x * U(0x85EBCA6B)) & M
+    x ^= x >> U(13); x = (x * U(0xC2B2AE35)) & M
+    h1 = x ^ (x >> U(16))
+    y = (h1 * U(0x27D4EB2F)) & M
+    h2 = y ^ (y >> U(15))
+    h = np.where((idx & U(2)) != 0, h2, h1)
+    field = np.where((idx & U(1)) != 0, h >> U(16), h & U(0xFFFF))
+    thresh = min(max(int(drop_p * 65536.0 + 0.5), 0), 65535)
+    return (field >= U(thresh)).astype(np.uint8)
