@@ -270,8 +270,10 @@ __device__ __forceinline__ void ln_bwd_row(const float (&xv)[NC][4], const T* dy
 
 // LayerNorm backward proper runs 4-wave workgroups.  At ~210 VGPRs two of them fit a CU, so 512 are resident at
 // once: the default cap (POLUS_LN_BWD_BLOCKS).  Their [blocks][3H] partials are reduced in fixed order by one
-// finalize launch; above FIN_SINGLE blocks (the round-1 grid of 1024) in two stages, groups of FIN_GROUP first.
-constexpr int BWD_WAVES = 4, BWD_MAX_BLOCKS = 1024, FIN_GROUP = 128, FIN_SINGLE = 512;
+// finalize launch up to POLUS_LN_FIN_SINGLE (512) rows, above that in two stages, groups of FIN_GROUP first.
+// Single-stream kernel time per step (profiles/r02_ln_bwd_reduce_shapes.txt): 1024 blocks / two stages 25.8 us +
+// 2 x 4.8 us per LayerNorm; 512 / two stages 22.0 + 2 x 4.7; 512 / one stage 21.8 + 4.8.
+constexpr int BWD_WAVES = 4, BWD_MAX_BLOCKS = 1024, FIN_GROUP = 128;
 template <typename T, int NC>
 __global__ __launch_bounds__(64 * BWD_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -312,8 +314,11 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
         P = min(pgroup, P - p0);
         out0 += (long)blockIdx.y * ncols;
     }
-    if (col < ncols)
+    if (col < ncols) {
+        // fixed order p = gy, gy + 16, ...; eight loads in flight (the rows are latency-, not bandwidth-bound)
+#pragma unroll 8
         for (int p = gy; p < P; p += 16) s += partial[(long)p * pstride + col];
+    }
     red[gy][cx] = s;
     __syncthreads();
     if (gy == 0 && col < ncols) {
@@ -707,7 +712,7 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
     else POLUS_FAIL("polus_layernorm_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd");
     int ncols = (wb ? 3 : 2) * H;
-    if (blocks > FIN_SINGLE) {
+    if (blocks > polus_cfg().ln_fin_single) {
         // two fixed-order stages: [blocks] -> [groups] -> result (a single stage would leave most
         // of the chip idle: ncols/64 workgroups walking 1024 rows each)
         int groups = (blocks + FIN_GROUP - 1) / FIN_GROUP;
