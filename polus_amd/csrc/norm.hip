@@ -578,10 +578,56 @@ __global__ __launch_bounds__(LN_THREADS) void embed_bwd_ln_kernel(const T* __res
     colacc_flush(acc, lds, partial, H, lane, wid, 0);
 }
 
-// word-table gradient, atomic form: one wave per token, 256 contiguous bytes per
-// wave-instruction (the shape global f32 atomics run at full rate for)
-__global__ __launch_bounds__(LN_THREADS) void embed_scatter_atomic_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
-                                                                   float* __restrict__ gword, int rows, int H, int vocab) {
+// word-table gradient, atomic form.  f32 atomics run at the memory side at ~1.3 TB/s when spread over rows but 14x
+// slower when many adders meet on ONE row (MI355X_MICROARCH.md, Global float atomics), and a quarter of a padded
+// batch is the [PAD] id, in runs at the end of every sequence.  Each wave therefore takes SC_RUN consecutive tokens,
+// loads all of their rows first (every row is needed exactly once; vmcnt retires in order, so a load issued after
+// an atomic would wait for it), combines the duplicates among them in registers -- the first occurrence sums, in
+// token order -- and issues one atomic row-add per distinct id, 256 contiguous bytes per wave-instruction.  No LDS,
+// no workgroup synchronisation, no wave sums more than SC_RUN rows.  168 -> 79 us with the combining alone at the
+// headline shape (runs of 4: 96 us, of 16: 140 us -- fewer, longer waves).  NC = ceil(H / 256) <= 4.
+constexpr int SC_RUN = 8, SC_WAVES = 8;
+template <int NC>
+__global__ __launch_bounds__(64 * SC_WAVES) void embed_scatter_atomic_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
+                                                                      float* __restrict__ gword, int rows, int H, int vocab) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long stride = (long)gridDim.x * SC_WAVES * SC_RUN;
+    for (long r0 = ((long)blockIdx.x * SC_WAVES + wid) * SC_RUN; r0 < rows; r0 += stride) {
+        int mine = -1;                                       // lanes 0 .. SC_RUN-1 hold the (clamped) ids of the run
+        if (lane < SC_RUN && r0 + lane < rows) { mine = ids[r0 + lane]; mine = mine < 0 ? 0 : (mine >= vocab ? vocab - 1 : mine); }
+        float row[SC_RUN][NC][4];
+#pragma unroll
+        for (int j = 0; j < SC_RUN; ++j) {
+            const bool valid = r0 + j < rows;                // wave-uniform
+            const float* src = de + (r0 + j) * H + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    row[j][c][k] = (valid && c * 256 + k * 64 + lane < H) ? src[c * 256 + k * 64] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < SC_RUN; ++t) {
+            const int id = __shfl(mine, t, 64);              // wave-uniform
+            const unsigned same = (unsigned)__ballot(mine == id);
+            if (id < 0 || (same & ((1u << t) - 1u))) continue;   // past the last row, or an earlier token owns this id
+            float* dst = gword + (long)id * H + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float acc = row[t][c][k];
+#pragma unroll
+                    for (int j = t + 1; j < SC_RUN; ++j)
+                        if ((same >> j) & 1u) acc += row[j][c][k];
+                    if (c * 256 + k * 64 + lane < H) atomicAdd(dst + c * 256 + k * 64, acc);
+                }
+        }
+    }
+}
+// any H: one wave per token, no combining
+__global__ __launch_bounds__(LN_THREADS) void embed_scatter_atomic_wide_kernel(const float* __restrict__ de, const int32_t* __restrict__ ids,
+                                                                        float* __restrict__ gword, int rows, int H, int vocab) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int row = blockIdx.x * WAVES + wid; row < rows; row += gridDim.x * WAVES) {
         int id = ids[row]; id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
@@ -821,7 +867,14 @@ extern "C" int polus_embed_ln_bwd(int dtype, const void* dy, const int32_t* ids,
     if (deterministic)
         hipLaunchKernelGGL(embed_scatter_owner_kernel, dim3(sblocks), dim3(LN_THREADS), 0, st, de, ids, gword, rows, H, vocab);
     else
-        hipLaunchKernelGGL(embed_scatter_atomic_kernel, dim3(sblocks), dim3(LN_THREADS), 0, st, de, ids, gword, rows, H, vocab);
+    {
+        const dim3 g(min((rows + SC_RUN * SC_WAVES - 1) / (SC_RUN * SC_WAVES), 4096)), b(64 * SC_WAVES);
+        if (H <= 256) hipLaunchKernelGGL(embed_scatter_atomic_kernel<1>, g, b, 0, st, de, ids, gword, rows, H, vocab);
+        else if (H <= 512) hipLaunchKernelGGL(embed_scatter_atomic_kernel<2>, g, b, 0, st, de, ids, gword, rows, H, vocab);
+        else if (H <= 768) hipLaunchKernelGGL(embed_scatter_atomic_kernel<3>, g, b, 0, st, de, ids, gword, rows, H, vocab);
+        else if (H <= 1024) hipLaunchKernelGGL(embed_scatter_atomic_kernel<4>, g, b, 0, st, de, ids, gword, rows, H, vocab);
+        else hipLaunchKernelGGL(embed_scatter_atomic_wide_kernel, dim3(sblocks), dim3(LN_THREADS), 0, st, de, ids, gword, rows, H, vocab);
+    }
     POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(scatter)");
     hipLaunchKernelGGL(embed_pos_grad_kernel, dim3(((long)S * H + 255) / 256), dim3(256), 0, st, de, gpos, B, S, H, accumulate);
     POLUS_CHECK_LAUNCH("polus_embed_ln_bwd(pos)");
