@@ -239,6 +239,54 @@ def test_ner_mlp_crf_step_matches_oracle():
     assert np.array_equal(model.inference(x).cpu().numpy(), ref_tags)
 
 
+def test_ner_mlp_dropout_crf_step_matches_oracle():
+    """polus/ner/models.py:46-66: the same head behind an input Dropout.  The mask is the engine's own generator
+    (taken from polus_dropout_mask with the layer's seed for its first training call); potentials, loss and every
+    gradient against the NumPy oracle applied to the masked input; inference ignores the dropout."""
+    from polus_amd import ops
+    from polus_amd.layers import Dropout
+    from polus_amd.ner.models import baselineNER_MLP_Dropout_CRF
+    B, S, C, p_drop = 4, 24, 3, 0.3
+    r = np.random.Generator(np.random.PCG64(19))
+    x = r.standard_normal((B, S, 768)).astype(np.float32)
+    tags = r.integers(0, C, size=(B, S))
+    y = np.eye(C, dtype=np.float32)[tags]
+    model = baselineNER_MLP_Dropout_CRF(sequence_length=S, output_classes=C, droupout_p=p_drop)
+    drop = model.layers[0]
+    assert isinstance(drop, Dropout) and drop.rate == p_drop and drop.calls == 0
+    w = {v.name: v.numpy().astype(np.float64) for v in model.trainable_weights}
+    n = [v.name for v in model.trainable_weights]
+    pot = model(x, training=True)
+    assert drop.calls == 1
+    seed = (drop.seed + 0x9E3779B1) & 0xFFFFFFFF
+    keep = host(ops.dropout_mask(seed, p_drop, B * S * 768)).astype(np.float64).reshape(B * S, 768)
+    assert 0.6 < keep.mean() < 0.8
+    q = 1.0 - round(p_drop * 65536) / 65536.0
+    xd = x.reshape(-1, 768).astype(np.float64) * keep / (1.0 - p_drop)
+    assert abs(1.0 / (1.0 - p_drop) - 1.0 / q) < 1e-4          # the scale the kernel uses is 1 / (1 - p)
+    loss = float(model.loss(y, pot))
+    u = xd @ w[n[0]].T + w[n[1]]
+    hdn = ob.swish(u)
+    pot_ref = (hdn @ w[n[2]].T + w[n[3]]).reshape(B, S, C)
+    assert_close(host(pot), pot_ref, 1e-4, "potentials behind dropout")
+    loss_ref, dpot, dT = ol.crf_nll_fwd(y, pot_ref, np.full(B, S), w[n[4]])
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    loss_obj = model.loss
+    loss_obj(y, pot)
+    model.backward(loss_obj.backward())
+    got = {v.name: host(v.grad) for v in model.trainable_weights}
+    d2 = dpot.reshape(-1, C)
+    assert_close(got[n[4]], dT, 2e-4, "transitions grad")
+    assert_close(got[n[2]], d2.T @ hdn, 2e-4, "dense2 grad")
+    du = (d2 @ w[n[2]]) * ob.swish_grad(u)
+    assert_close(got[n[0]], du.T @ xd, 2e-4, "dense1 grad (masked input)")
+    # inference: no dropout, Viterbi tags of the undropped potentials
+    u0 = x.reshape(-1, 768).astype(np.float64) @ w[n[0]].T + w[n[1]]
+    pot0 = (ob.swish(u0) @ w[n[2]].T + w[n[3]]).reshape(B, S, C)
+    assert np.array_equal(model.inference(x).cpu().numpy(), ol.crf_viterbi(pot0, np.full(B, S), w[n[4]]))
+    assert drop.calls == 1
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_ir_dense_retrieval_trainer_step(mode):
     """polus/ir/training.py:47-117: frozen encoders in forward_without_grads, trainable projections +
