@@ -87,7 +87,13 @@ def save_training_state(trainer, path):
     SaveModelCallback does not keep (polus/callbacks.py:264-313 saves weights only): the f32 master
     parameters of every arena the trainer updates, the Adam moments, the optimizer's iteration count
     (the learning-rate schedule's argument), the trainer's step / micro-step counters and the models'
-    dropout counters.  One `<path>.state.npz`; written by rank 0's caller."""
+    dropout counters.  One `<path>.state.npz`; written by rank 0's caller.  Data-parallel runs on the
+    reduce-scatter scheme keep each rank's Adam moments current only on the slices it owns: every rank calls
+    `trainer.sync_optimizer_state()` (a collective) first, then rank 0 saves -- saving unsynchronised moments
+    is refused rather than written."""
+    if getattr(trainer, "use_horovod", False) and not getattr(trainer, "_opt_state_synced", True):
+        raise RuntimeError("save_training_state: this rank's optimizer moments are current only on its own arena slices "
+                           "(data-parallel reduce-scatter scheme); call trainer.sync_optimizer_state() on every rank first")
     arenas = trainer._arenas()
     opt = trainer.optimizer
     out = {"n_arenas": np.int64(len(arenas)), "iterations": np.int64(getattr(opt, "iterations", 0)),

@@ -264,6 +264,7 @@ class BaseTrainer:
             # every rank updates its slices of the arena, then the updated f32 parameters travel back
             arena = self._arenas()[0]
             self.optimizer.apply_gradients(list(zip(grads, self.trainable_weights)), _ranges=owned, _refresh=False)
+            self._opt_state_synced = False       # this rank's Adam moments are now current on its own slices only
             reducers[0].allgather(arena.params)
             arena.refresh_shadow()
         elif split_at is not None:
@@ -284,8 +285,26 @@ class BaseTrainer:
         for k, v in config.items():
             self.train_config[k] = v
 
+    def sync_optimizer_state(self):
+        """Data-parallel runs on the reduce-scatter scheme update, on every rank, only the arena slices that rank
+        owns, so a rank's optimizer moments are current only there.  This all-gathers the owned slices of every
+        moment: afterwards each rank holds the full, current optimizer state, as it does under Horovod.  Needed
+        before anything reads whole moments -- the per-epoch broadcast of polus/training.py:208-211 (rank 0's
+        copy would overwrite the other ranks' current slices with stale ones) and save_training_state.
+        Collective: every rank must call it.  No-op in a single process, on the all-reduce scheme, or when
+        nothing has been updated since the last call."""
+        if not self.use_horovod or self._dp_mode() != "rs" or getattr(self, "_opt_state_synced", True):
+            return
+        arena = self._arenas()[0]
+        if hasattr(self.optimizer, "_slots"):
+            reducer = self._reducer(arena)
+            for moment in self.optimizer._slots(arena):
+                reducer.allgather(moment)
+        self._opt_state_synced = True
+
     def broadcast_init_vars(self):
         """polus/training.py:208-211."""
+        self.sync_optimizer_state()
         hvd.broadcast_variables(self.trainable_weights, root_rank=0)
         hvd.broadcast_variables(self.optimizer.variables(), root_rank=0)
 

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1]
-    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # rs | allreduce | rs_bf16 | rs_accum2
+    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # rs | allreduce | rs_bf16 | rs_accum2 | rs_epochs2
     os.environ["POLUS_DP_MODE"] = "allreduce" if mode == "allreduce" else "rs"
     if mode == "rs_bf16":
         os.environ["POLUS_DP_BF16"] = "1"
@@ -35,7 +35,8 @@ def main():
         params = {k: v + 0.01 for k, v in params.items()}
     model = build_model(ocfg, params, head_w, head_b, "f32")
     steps = 3
-    opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps, 1e-3), weight_decay_rate=0.01)
+    epochs = 2 if mode == "rs_epochs2" else 1     # the second epoch re-broadcasts weights AND optimizer variables from rank 0
+    opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps * epochs, 1e-3), weight_decay_rate=0.01)
     trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
     assert trainer.use_horovod
     accum = 2 if mode == "rs_accum2" else 1
@@ -51,8 +52,9 @@ def main():
     calls = []
     orig = opt.apply_gradients
     opt.apply_gradients = lambda gv, **kw: (calls.append((len(list(gv)) if not isinstance(gv, list) else len(gv), kw)), orig(gv, **kw))[1]
-    trainer.train(batches, epochs=1, callbacks=[])
+    trainer.train(batches, epochs=epochs, callbacks=[])
     assert trainer._dp_mode() == ("allreduce" if mode == "allreduce" else "rs")
+    steps *= epochs
     if mode == "allreduce":
         # the update is split around the last all-reduce bucket: two launches per step, every variable once
         assert len(calls) == 2 * steps and all(calls[2 * k][0] + calls[2 * k + 1][0] == len(trainer.trainable_weights)
@@ -67,6 +69,18 @@ def main():
     # the parent compares parameters, which depend on every step's averaged gradients
     flat = model.arena.params.detach().float().cpu().numpy()
     np.save(f"{out}.rank{rank}.npy", flat)
+    if mode == "rs_epochs2":
+        # the moments are sharded after the last step; saving them unsynchronised is refused, the collective sync
+        # makes them whole and identical on both ranks (the parent compares them with the single-process run)
+        import pytest
+        from polus_amd.checkpoint import save_training_state
+        with pytest.raises(RuntimeError, match="sync_optimizer_state"):
+            save_training_state(trainer, out + f".rank{rank}")
+        trainer.sync_optimizer_state()
+        m_, v_ = opt._slots(model.arena)
+        np.save(f"{out}.rank{rank}.m.npy", m_.detach().float().cpu().numpy())
+        np.save(f"{out}.rank{rank}.v.npy", v_.detach().float().cpu().numpy())
+        save_training_state(trainer, out + f".rank{rank}")
     comm.barrier()
     comm.shutdown()
     print(f"rank {rank} OK", flush=True)

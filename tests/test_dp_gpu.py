@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["rs", "allreduce", "rs_accum2", "rs_bf16"])
+@pytest.mark.parametrize("mode", ["rs", "allreduce", "rs_accum2", "rs_bf16", "rs_epochs2"])
 def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
     from polus_amd.losses import SparseCategoricalCrossentropy
     from polus_amd.optimizers import AdamWeightDecay
@@ -53,13 +53,14 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
     model = build_model(ocfg, params, head_w, head_b, "f32")
     start = model.arena.params.detach().float().cpu().numpy().copy()
     steps = 3
-    opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps, 2e-3), weight_decay_rate=0.01)
+    epochs = 2 if mode == "rs_epochs2" else 1
+    opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps * epochs, 2e-3), weight_decay_rate=0.01)
     trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
     batches = []
     for s in range(steps):
         ids, mask, tt, labels = synth_batch(ocfg, 4, 16, 4, 420 + s)
         batches.append(({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels))
-    trainer.train(batches, epochs=1, callbacks=[])
+    trainer.train(batches, epochs=epochs, callbacks=[])
     single = model.arena.params.detach().float().cpu().numpy()
     moved = np.abs(single - start).max()
     n = min(single.size, r0.size)              # the 2-rank arena is padded to whole 64 x world element units
@@ -73,6 +74,18 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
         assert diff.mean() < 0.05 * moved, (diff.max(), diff.mean(), moved)
     else:
         assert diff.max() < 0.02 * moved and diff.mean() < 1e-3 * moved, (diff.max(), diff.mean(), moved)
+    if mode == "rs_epochs2":
+        # after trainer.sync_optimizer_state() both ranks hold the SAME, whole Adam moments, and they are the
+        # single-process moments (the per-epoch broadcast from rank 0 must not have replaced rank 1's slices
+        # with rank 0's never-updated copies of them)
+        sm, sv = (t.detach().float().cpu().numpy() for t in opt._slots(model.arena))
+        for name, ref in (("m", sm), ("v", sv)):
+            a, b = np.load(f"{out}.rank0.{name}.npy"), np.load(f"{out}.rank1.{name}.npy")
+            assert np.array_equal(a, b), f"Adam {name} differs between the ranks after the sync"
+            assert np.abs(a[:n]).max() > 0 and not a[n:].any()
+            err = np.abs(a[:n] - ref[:n])
+            assert err.max() < 0.02 * np.abs(ref[:n]).max() and err.mean() < 2e-3 * np.abs(ref[:n]).mean(), (name, err.max(), err.mean())
+        assert os.path.exists(out + ".rank0.state.npz")
 
 
 def test_native_rccl_plane_world_1():
