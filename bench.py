@@ -302,7 +302,7 @@ def main():
                                    f"(BASELINE.json configs[2] per-GPU shape), AdamW lr 5e-5 wd 0.01 warm-up 10%, "
                                    f"dropout {args.dropout} (hidden + attention), random-init weights",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
-                       "grad_allreduce": (f"bucketed RCCL {'reduce-scatter (f32, 64 MB buckets) overlapped with backward -> AdamW on the owned slices -> all-gather of the parameters' if os.environ.get('POLUS_DP_MODE', 'rs') != 'allreduce' else 'all-reduce (f32, 64 MB buckets) overlapped with backward'}; data plane: {comm._STATE['backend']}") if world > 1 else "none"},
+                       "grad_allreduce": (f"bucketed RCCL {'reduce-scatter (f32, 64 MB buckets) overlapped with backward -> AdamW on the owned slices -> all-gather of the parameters' if os.environ.get('POLUS_DP_MODE', 'allreduce') == 'rs' else 'all-reduce (f32, 64 MB buckets) fired inside backward, the fused AdamW of each bucket queued behind it'}; data plane: {comm._STATE['backend']}") if world > 1 else "none"},
             "step_mfma_frac": head["step_mfma_frac"], "step_tflops_per_gpu": head["step_tflops_per_gpu"],
             "loss_first": head["loss_first"], "loss_last": head["loss_last"],
         }

@@ -18,12 +18,13 @@ order, so `GradBucketReducer` cuts it into contiguous buckets from the END (the 
 them) and starts a bucket's collective as soon as the model reports everything above its lower edge
 final.  Two exchange schemes:
 
-* `allreduce`: all-reduce (SUM) per bucket; every rank then runs the full AdamW update;
-* `rs` (default on the data plane above): reduce-scatter per bucket -- rank r ends up with the sum of
-  slice r of every bucket -- each rank runs AdamW on its slices only (1/N of the optimizer's HBM
-  traffic), then one all-gather per bucket returns the updated f32 parameters to everyone.  On the xGMI
-  mesh a reduce-scatter / all-gather pair moves bytes/N per link and phase over all links at once
-  (SURVEY.md §5), where a ring all-reduce pushes 2 (N-1)/N of the bytes through one link per direction.
+* `allreduce` (default): all-reduce (SUM) per bucket, buckets cut at variable boundaries; `on_launched` lets the
+  trainer queue the AdamW update of a bucket's variables behind that bucket's completion event, so exchange and
+  update both run beside the rest of backward (polus_amd/training.py _UpdateBehindAllReduce);
+* `rs` (`POLUS_DP_MODE=rs`): reduce-scatter per bucket -- rank r ends up with the sum of slice r of every
+  bucket -- each rank runs AdamW on its slices only (1/N of the optimizer's HBM traffic), then one all-gather
+  per bucket returns the updated f32 parameters to everyone.  Half the bytes during backward, but the all-gather
+  can only follow the update and nothing hides it (DESIGN.md §5 has the arithmetic behind the default).
   Optional bf16 transport of the gradients (`POLUS_DP_BF16=1`) halves the reduce-scatter bytes.
 
 The 1/world (and 1/accumulation) factor is folded into the optimizer's gradient scale instead of a
@@ -388,6 +389,7 @@ class GradBucketReducer:
         self._ready_lo = n
         self._works = []
         self.launched_bytes = 0
+        self.on_launched = None         # optional callback(lo, hi, work) right after a bucket's collective is queued
 
     # ---- slices this rank owns after the reduce-scatter: slice `rank` of every bucket
     def owned_ranges(self):
@@ -433,6 +435,8 @@ class GradBucketReducer:
             # reduces beside whatever backward launches next
             self._works.append(self._launch_one(lo, hi))
             self._next += 1
+            if self.on_launched is not None:
+                self.on_launched(lo, hi, self._works[-1])
 
     def finish(self, keep_last=False):
         """Flush what is left and make the current stream wait for every bucket.

@@ -62,6 +62,26 @@ class _UpdateInBackward:
         torch.cuda.current_stream().wait_event(self.done)
 
 
+class _UpdateBehindAllReduce(_UpdateInBackward):
+    """Data-parallel steps on the all-reduce scheme: the reducer fires a bucket's all-reduce as soon as backward
+    has produced everything in it; the fused optimizer update of the variables inside that bucket is queued on the
+    update stream right behind the all-reduce's completion event, so it too runs beside the rest of backward.
+    Buckets are cut at variable boundaries, so every variable belongs to exactly one of them.  When the all-reduce
+    has completed, the layers that read these parameters have completed as well (the collective waited for the
+    compute stream) -- no further fence is needed.  What stays exposed after backward is the last bucket (the
+    embeddings) and its update."""
+
+    def on_bucket(self, lo, hi, work):
+        vs = [v for v in self.vars if id(v) in self.left and lo <= v.offset and v.offset + v.size <= hi]
+        with _lib.stream_scope(self.stream):
+            work.wait()                      # the update stream (not the compute stream) waits for this bucket
+            if vs:
+                self.trainer.optimizer.apply_gradients([(v.grad, v) for v in vs], _advance=self.first, _refresh=False)
+                self.first = False
+        for v in vs:
+            del self.left[id(v)]
+
+
 class BaseTrainer:
     """polus/training.py:14-338."""
 
@@ -123,10 +143,13 @@ class BaseTrainer:
         return out
 
     def _dp_mode(self):
-        """How the gradients of this trainer are exchanged (decided once): "rs" = reduce-scatter -> AdamW on
-        the owned slices -> all-gather of the parameters, when one fused optimizer sweeps one arena and
-        nothing needs every gradient on every rank (no post_process_grads, no global-norm clipping);
-        else "allreduce".  POLUS_DP_MODE=allreduce forces the latter."""
+        """How the gradients of this trainer are exchanged (decided once).  Default "allreduce": bucketed
+        all-reduce fired inside backward, each bucket's fused AdamW queued behind it (_UpdateBehindAllReduce) --
+        everything but the last bucket hides under backward.  POLUS_DP_MODE=rs selects reduce-scatter -> AdamW
+        on the owned slices -> all-gather of the parameters (half the bytes during backward and 1/N of the
+        optimizer traffic, but the all-gather of the f32 parameters is exposed after the update: (N-1)/N x
+        438 MB over the links, ~2.9 ms at N = 2), when one fused optimizer sweeps one arena and nothing
+        needs every gradient on every rank (no post_process_grads, no global-norm clipping)."""
         m = getattr(self, "_dp_mode_cached", None)
         if m is None:
             arenas = self._arenas()
@@ -134,7 +157,7 @@ class BaseTrainer:
                   self.post_process_grads is None and hasattr(arenas[0], "size") and
                   arenas[0].grads.numel() % (64 * hvd.size()) == 0 and
                   all(v.arena is arenas[0] for v in self.trainable_weights) and
-                  os.environ.get("POLUS_DP_MODE", "rs") != "allreduce")
+                  os.environ.get("POLUS_DP_MODE", "allreduce") == "rs")
             m = self._dp_mode_cached = "rs" if ok else "allreduce"
         return m
 
@@ -156,6 +179,24 @@ class BaseTrainer:
                   self.post_process_grads is None and hasattr(arenas[0], "refresh_transposed") and
                   arenas[0].grads.is_cuda and all(v.arena is arenas[0] for v in self.trainable_weights))
             u = self._updater_cached = _UpdateInBackward(self, arenas[0]) if ok else None
+        return u
+
+    def _updater_dp(self, reducer):
+        """The per-bucket optimizer update behind each all-reduce (_UpdateBehindAllReduce): all-reduce scheme, GPU
+        arena, the fused Adam, nothing that needs every gradient at once.  POLUS_UPDATE_IN_BACKWARD=0 keeps the
+        update after backward (split around the last bucket)."""
+        if self._dp_mode() != "allreduce" or reducer.mode == "rs":
+            return None
+        key = tuple(id(v) for v in self.trainable_weights)
+        u = getattr(self, "_updater_dp_cached", False)
+        if u is False or getattr(self, "_updater_dp_key", None) != key:
+            self._updater_dp_key = key
+            arena = self._arenas()[0]
+            ok = (os.environ.get("POLUS_UPDATE_IN_BACKWARD", "1") != "0" and isinstance(self.optimizer, Adam) and
+                  hasattr(self.optimizer, "grad_scale") and not self.optimizer.global_clipnorm and
+                  self.post_process_grads is None and hasattr(arena, "refresh_transposed") and arena.grads.is_cuda and
+                  all(v.arena is arena for v in self.trainable_weights) and getattr(self, "_graphed", None) is None)
+            u = self._updater_dp_cached = _UpdateBehindAllReduce(self, arena) if ok else None
         return u
 
     def _reducer(self, arena):
@@ -203,7 +244,7 @@ class BaseTrainer:
 
         # The exchange starts inside backward: on the micro-step that completes an accumulation the model
         # reports each gradient window as it becomes final and the reducer fires the buckets above it.
-        reducers = []
+        reducers, dp_updater = [], None
         if self.use_horovod and last:
             arenas = self._arenas()
             if len(arenas) == 1 and hasattr(self.model, "grad_ready_hook"):
@@ -211,6 +252,11 @@ class BaseTrainer:
                 r.begin()
                 self.model.grad_ready_hook = r.on_ready
                 reducers = [r]
+                dp_updater = self._updater_dp(r)
+                if dp_updater is not None:
+                    self.optimizer.grad_scale = 1.0 / (hvd.size() * accum)
+                    dp_updater.begin()
+                    r.on_launched = dp_updater.on_bucket
         updater = self._updater() if (last and not self.use_horovod) else None
         if updater is not None:
             self.optimizer.grad_scale = 1.0 / accum
@@ -236,6 +282,14 @@ class BaseTrainer:
             if self._dp_mode() == "rs":
                 reducers[0].finish()
                 owned = reducers[0].owned_ranges()
+            elif dp_updater is not None:
+                # every bucket's update was queued behind its all-reduce; flush the rest and join
+                reducers[0].finish()
+                reducers[0].on_launched = None
+                if hasattr(self.model, "grad_ready_hook"):
+                    self.model.grad_ready_hook = None
+                dp_updater.finish()
+                return loss_value
             else:
                 # One arena, a fused optimizer and nothing that needs all gradients at once: keep the last
                 # bucket (the embeddings) in flight and update everything above it meanwhile.

@@ -13,8 +13,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1]
-    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # rs | allreduce | rs_bf16 | rs_accum2 | rs_epochs2
-    os.environ["POLUS_DP_MODE"] = "allreduce" if mode == "allreduce" else "rs"
+    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # (rs | allreduce)[_accum2 | _epochs2] | rs_bf16
+    scheme = "allreduce" if mode.startswith("allreduce") else "rs"
+    os.environ["POLUS_DP_MODE"] = scheme
     if mode == "rs_bf16":
         os.environ["POLUS_DP_BF16"] = "1"
     from polus_amd import comm
@@ -35,11 +36,11 @@ def main():
         params = {k: v + 0.01 for k, v in params.items()}
     model = build_model(ocfg, params, head_w, head_b, "f32")
     steps = 3
-    epochs = 2 if mode == "rs_epochs2" else 1     # the second epoch re-broadcasts weights AND optimizer variables from rank 0
+    epochs = 2 if mode.endswith("_epochs2") else 1     # the second epoch re-broadcasts weights AND optimizer variables from rank 0
     opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps * epochs, 1e-3), weight_decay_rate=0.01)
     trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
     assert trainer.use_horovod
-    accum = 2 if mode == "rs_accum2" else 1
+    accum = 2 if mode.endswith("_accum2") else 1
     trainer.grad_accum_steps = accum
     os.environ["POLUS_BUCKET_MB"] = "0.05"        # several buckets even for this small model
     mine = list(shard(range(4), 2, rank))                  # sample i -> rank i mod 2
@@ -53,13 +54,19 @@ def main():
     orig = opt.apply_gradients
     opt.apply_gradients = lambda gv, **kw: (calls.append((len(list(gv)) if not isinstance(gv, list) else len(gv), kw)), orig(gv, **kw))[1]
     trainer.train(batches, epochs=epochs, callbacks=[])
-    assert trainer._dp_mode() == ("allreduce" if mode == "allreduce" else "rs")
+    assert trainer._dp_mode() == scheme
     steps *= epochs
-    if mode == "allreduce":
-        # the update is split around the last all-reduce bucket: two launches per step, every variable once
-        assert len(calls) == 2 * steps and all(calls[2 * k][0] + calls[2 * k + 1][0] == len(trainer.trainable_weights)
-                                               for k in range(steps)), calls
-        assert all(calls[2 * k + 1][1].get("_advance") is False for k in range(steps))
+    if scheme == "allreduce":
+        # the update of every bucket is queued behind its all-reduce: one launch per bucket and step, every
+        # variable exactly once per step, the step counter advanced by the first launch only
+        r = trainer._reducer(model.arena)
+        nb = len(r.buckets)
+        assert nb > 1 and len(calls) == nb * steps, (nb, len(calls))
+        for k in range(steps):
+            per_step = calls[nb * k:nb * (k + 1)]
+            assert sum(c[0] for c in per_step) == len(trainer.trainable_weights), per_step
+            assert per_step[0][1].get("_advance") is True and all(c[1].get("_advance") is False for c in per_step[1:])
+        assert opt.iterations == steps
     else:
         # one launch per optimizer step, on the windows this rank owns after the reduce-scatter
         assert len(calls) == steps and all(c[1].get("_ranges") for c in calls), calls

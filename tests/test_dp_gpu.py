@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["rs", "allreduce", "rs_accum2", "rs_bf16", "rs_epochs2"])
+@pytest.mark.parametrize("mode", ["allreduce", "allreduce_accum2", "allreduce_epochs2", "rs", "rs_accum2", "rs_bf16", "rs_epochs2"])
 def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
     from polus_amd.losses import SparseCategoricalCrossentropy
     from polus_amd.optimizers import AdamWeightDecay
@@ -53,7 +53,7 @@ def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
     model = build_model(ocfg, params, head_w, head_b, "f32")
     start = model.arena.params.detach().float().cpu().numpy().copy()
     steps = 3
-    epochs = 2 if mode == "rs_epochs2" else 1
+    epochs = 2 if mode.endswith("_epochs2") else 1
     opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps * epochs, 2e-3), weight_decay_rate=0.01)
     trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
     batches = []
