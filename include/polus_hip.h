@@ -74,8 +74,13 @@ int polus_set_dynamic_params(const void* dev_block16);
  *                 v += resid[m][n]; ACCUM_C: v += C[m][n]; C = v.
  * c_dtype is the element type of C / resid / aux... C only: resid and aux use `dtype`.
  * split_k > 1 writes f32 partial slabs to `workspace` and reduces them in a second,
- * order-fixed kernel (bitwise reproducible); only bias/ACCUM_C epilogues are allowed then. */
+ * order-fixed kernel (bitwise reproducible).  With bf16 K-contiguous operands and a bf16 C the reduce
+ * applies the whole epilogue (residual, activation forward / backward, dropout); otherwise only
+ * bias / ACCUM_C epilogues are allowed with split_k > 1.
+ * polus_gemm_auto_split: the number of K slices the library recommends for a bf16 Dense GEMM of this size
+ * (1 = none): > 1 when 256-row tiles would fill less than half of the chip (a few thousand tokens, N = 768). */
 size_t polus_gemm_workspace_bytes(int M, int N, int split_k);
+int polus_gemm_auto_split(int M, int N, int K);
 int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
                const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                int M, int N, int K, float alpha,

@@ -25,6 +25,7 @@ SIGNATURES = {
     "polus_reload_env": (_i, []),
     "polus_set_dynamic_params": (_i, [_vp]),
     "polus_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "polus_gemm_auto_split": (_i, [_i, _i, _i]),
     "polus_gemm": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,
                         _vp, _vp, _l, _vp, _l, _i, _i, _i, _vp, _sz, _vp]),
     "polus_gemm_dropout": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _f,

@@ -227,6 +227,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     *c = from_f<TC>(s);
 }
 
+// order-fixed split-K reduction with the FULL epilogue of the unsplit kernels (bf16 engine, K-contiguous operands,
+// bf16 C): a thread sums the slabs of four columns in slice order and hands them to pgemm::epilogue_tile -- bias,
+// activation (+ pre-activation store), activation gradient, dropout, residual.  Lets a Dense GEMM that would fill
+// less than half of the chip with 256-row tiles (a few thousand tokens, N = 768) run its K range in several slices.
+template <bool DROP>
+__global__ __launch_bounds__(256) void splitk_reduce_epi_kernel(GemmArgs p, const float* __restrict__ slabs, int splits) {
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    const int nq = (p.N + 3) / 4;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long)p.M * nq) return;
+    const int m = (int)(q / nq), n = (int)(q % nq) * 4;
+    const long total = (long)p.M * p.N;
+    const float* s0 = slabs + (long)m * p.N + n;
+    const int nvalid = p.N - n;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < splits; ++z) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        ld4x<float>(s0 + (long)z * total, v, (p.N & 3) == 0, nvalid);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    epilogue_tile<bf16_t, bf16_t, DROP>(p, acc, m, n, 0);
+}
+
 template <typename T, bool A_KS, bool B_KS, typename TC, bool VEC, bool DROP = false>
 int launch_v(const GemmArgs& a, dim3 grid, hipStream_t st) {
     static bool attr_done = false;  // per instantiation
@@ -310,6 +333,24 @@ static int pp_tile(int M, int N, int K, int mode, bool vec16) {
     return best >= 0.70 ? best_tn : 0;
 }
 
+// Number of K slices a bf16 Dense GEMM (both operands K-contiguous, bf16 C, any epilogue) should be cut into: 1 when a
+// 256-wide ping-pong tile fills the chip or the 256 x 128 ring tiles take a quarter or more of its 2 x #CU slots;
+// otherwise enough slices to bring the ring launch to ~3/4 of the slots, each at least 512 deep (<= 8).  Measured in
+// the step (profiles/r02_ab_auto_split.txt): at 19 % of the slots (4096 tokens, N = 768: 4 slices) the step gains
+// 2 %; at 37 % (8192 tokens: 2 slices) it loses 3 % -- the f32 slabs cost more than the idle CUs.  The caller passes
+// the result as split_k with polus_gemm_workspace_bytes(M, N, split_k) of workspace.
+extern "C" int polus_gemm_auto_split(int M, int N, int K) {
+    if (!polus_cfg().gemm_auto_split || M < 256 || N < 128 || K % 64 != 0 || K < 1024) return 1;
+    if (pp_tile(M, N, K, 0, true)) return 1;
+    const long slots = 2L * polus_num_cus();
+    const long t = (long)((M + 255) / 256) * ((N + 127) / 128);
+    if (4 * t >= slots) return 1;
+    long s = (slots * 3 / 4) / t;
+    if (s > K / 512) s = K / 512;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : (int)s;
+}
+
 static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
                      const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                      int M, int N, int K, float alpha,
@@ -335,7 +376,6 @@ extern "C" int polus_gemm_dropout(int dtype, int a_layout, int b_layout, int c_d
                                   int act, int flags, int split_k, void* workspace, size_t workspace_bytes,
                                   float drop_p, uint32_t seed, void* stream) {
     POLUS_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "polus_gemm_dropout: need 0 <= p < 1 (got %f)", drop_p);
-    POLUS_REQUIRE(split_k <= 1, "polus_gemm_dropout: split_k is not supported with dropout");
     POLUS_REQUIRE((long)M * N < (1LL << 32), "polus_gemm_dropout: M*N must fit 32 bits");
     if (drop_p > 0.0f) flags |= POLUS_GEMM_DROPOUT; else flags &= ~POLUS_GEMM_DROPOUT;
     return gemm_impl(dtype, a_layout, b_layout, c_dtype, A, lda, B, ldb, C, ldc, M, N, K, alpha, bias, resid, ldr,
@@ -365,8 +405,10 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     int nkt = (K + bk - 1) / bk;
     if (split_k > nkt) split_k = nkt;
     if (split_k > 1) {
-        POLUS_REQUIRE(!resid && !aux && !(flags & (POLUS_GEMM_ACT_FWD | POLUS_GEMM_ACT_BWD)),
-                      "polus_gemm: split_k supports only bias / ACCUM_C epilogues");
+        const bool epi = resid || aux || (flags & (POLUS_GEMM_ACT_FWD | POLUS_GEMM_ACT_BWD | POLUS_GEMM_DROPOUT));
+        POLUS_REQUIRE(!epi || (dtype == POLUS_BF16 && c_dtype == POLUS_BF16 && a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG &&
+                               !(flags & POLUS_GEMM_ACCUM_C)),
+                      "polus_gemm: split_k with a residual / activation / dropout epilogue needs bf16 K-contiguous operands and a bf16 C");
         if (!workspace || workspace_bytes < polus_gemm_workspace_bytes(M, N, split_k)) {
             polus_set_error("polus_gemm: workspace %zu < %zu", workspace_bytes, polus_gemm_workspace_bytes(M, N, split_k));
             return POLUS_ERR_WORKSPACE;
@@ -405,6 +447,32 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.c_split_stride = 0;
     a.colsum_a = nullptr;
     const bool both_kc = a_layout == POLUS_K_CONTIG && b_layout == POLUS_K_CONTIG;
+    const bool fast_bf16 = dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !polus_cfg().gemm_v1;
+    const bool epi_split = split_k > 1 && (resid || aux || (flags & (POLUS_GEMM_ACT_FWD | POLUS_GEMM_ACT_BWD | POLUS_GEMM_DROPOUT)));
+    if (epi_split && fast_bf16 && both_kc && c_dtype == POLUS_BF16) {
+        GemmArgs s = a;              // slabs: plain f32 stores of every K slice ...
+        s.C = a.partial; s.ldc = N; s.c_split_stride = (long)M * N; s.partial = nullptr;
+        s.alpha = 1.0f; s.bias = nullptr; s.flags = 0; s.resid = nullptr; s.aux = nullptr;
+        s.epi_vec = (N % 4 == 0); s.epi_vec16 = (N % 4 == 0) && polus_aligned16(a.partial);
+        rc = polus_launch_gemm_ring(s, 1, 0, 0, splits_eff, st);
+        if (rc != POLUS_OK) return rc;
+        GemmArgs e = a;              // ... then the whole epilogue on their sum
+        e.partial = nullptr;
+        const long quads = (long)M * ((N + 3) / 4);
+        const int blocks = (int)((quads + 255) / 256);
+        if (flags & POLUS_GEMM_DROPOUT)
+            hipLaunchKernelGGL(splitk_reduce_epi_kernel<true>, dim3(blocks), dim3(256), 0, st, e, a.partial, splits_eff);
+        else
+            hipLaunchKernelGGL(splitk_reduce_epi_kernel<false>, dim3(blocks), dim3(256), 0, st, e, a.partial, splits_eff);
+        POLUS_CHECK_LAUNCH("polus_gemm(splitk_reduce_epi)");
+        return POLUS_OK;
+    }
+    if (epi_split) {                 // not on the fast path (small or unaligned problem): one slice, in-kernel epilogue
+        split_k = 1; a.partial = nullptr;
+        a.k_per_split = nkt * bk;
+        grid = dim3(tiles, 1, 1);
+        splits_eff = 1;
+    }
     if (flags & POLUS_GEMM_DROPOUT) {
         // forward Dense only: K-contiguous operands, C in the compute dtype
         POLUS_REQUIRE(both_kc && c_dtype == dtype, "polus_gemm_dropout: needs K-contiguous operands and c_dtype == dtype");

@@ -79,7 +79,7 @@ def gemm_dx(dy, w, dx, **kw):
     K-strided operand (k-major LDS image, transposing LDS reads)."""
     wt = w.compute_t
     if wt is not None:
-        return ops.gemm(dy, wt, dx, **kw)
+        return ops.gemm(dy, wt, dx, split_k="auto", **kw)
     return ops.gemm(dy, w.compute, dx, b_layout=ops.K_STRIDED, **kw)
 
 
@@ -180,10 +180,10 @@ class Dense(Layer):
         if self.activation:
             assert odt == x2.dtype, "an activated Dense keeps the compute dtype"
             u = self._buf("u", (rows, self.units), x2.dtype, x2.device)
-            ops.gemm(x2, self.w.compute, y, bias=bias, aux=u, act=self.activation, flags=ops.GEMM_ACT_FWD)
+            ops.gemm(x2, self.w.compute, y, bias=bias, aux=u, act=self.activation, flags=ops.GEMM_ACT_FWD, split_k="auto")
             self._u = u
         else:
-            ops.gemm(x2, self.w.compute, y, bias=bias)
+            ops.gemm(x2, self.w.compute, y, bias=bias, split_k="auto")
         self._x = x2
         return y.view(*lead, self.units)
 

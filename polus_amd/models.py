@@ -189,12 +189,12 @@ class BertLayer:
         u, f = b("u", (T, I)), b("f", (T, I))
         z2, y = b("z2", (T, H)), b("y", (T, H))
         m2, r2 = b("m2", (T,), torch.float32), b("r2", (T,), torch.float32)
-        ops.gemm(x, self.qkv_w.compute, qkv, bias=self.qkv_b.value)
+        ops.gemm(x, self.qkv_w.compute, qkv, bias=self.qkv_b.value, split_k="auto")
         ops.attention_fwd(qkv, mask, ctx, lse, B, S, A, drop_p=p_att, seed=seeds[0])
-        ops.gemm(ctx, self.out_w.compute, z1, bias=self.out_b.value, resid=x, drop_p=p_hid, seed=seeds[1])
+        ops.gemm(ctx, self.out_w.compute, z1, bias=self.out_b.value, resid=x, drop_p=p_hid, seed=seeds[1], split_k="auto")
         ops.layernorm_fwd(z1, self.ln1_g.value, self.ln1_b.value, a1, m1, r1, cfg.layer_norm_eps)
-        ops.gemm(a1, self.ffn1_w.compute, f, bias=self.ffn1_b.value, aux=u, act="gelu", flags=ops.GEMM_ACT_FWD)
-        ops.gemm(f, self.ffn2_w.compute, z2, bias=self.ffn2_b.value, resid=a1, drop_p=p_hid, seed=seeds[2])
+        ops.gemm(a1, self.ffn1_w.compute, f, bias=self.ffn1_b.value, aux=u, act="gelu", flags=ops.GEMM_ACT_FWD, split_k="auto")
+        ops.gemm(f, self.ffn2_w.compute, z2, bias=self.ffn2_b.value, resid=a1, drop_p=p_hid, seed=seeds[2], split_k="auto")
         ops.layernorm_fwd(z2, self.ln2_g.value, self.ln2_b.value, y, m2, r2, cfg.layer_norm_eps)
         self._stash = (x, mask, B, S, p_hid, p_att, seeds)
         return y

@@ -76,12 +76,16 @@ def set_env(name, value=None):
     else:
         os.environ[name] = str(value)
     check(_lib.load().polus_reload_env(), "polus_reload_env")
+    _AUTO_SPLIT.clear()
 
 
 def _req_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.PolusHipError("polus_amd ops need device (HBM) tensors; there is no CPU path")
+
+
+_AUTO_SPLIT = {}
 
 
 def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=None, alpha=1.0,
@@ -107,6 +111,15 @@ def gemm(a, b, out, *, a_layout=K_CONTIG, b_layout=K_CONTIG, M=None, N=None, K=N
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
     ws = None
     ws_bytes = 0
+    if split_k == "auto":
+        # the library's recommendation for a bf16 Dense GEMM (K-contiguous operands, bf16 C); 1 for everything else
+        split_k = 1
+        if (a.dtype == torch.bfloat16 and out.dtype == a.dtype and a_layout == K_CONTIG and b_layout == K_CONTIG
+                and not (flags & GEMM_ACCUM_C)):
+            key = (M, N, K)
+            split_k = _AUTO_SPLIT.get(key)
+            if split_k is None:
+                split_k = _AUTO_SPLIT[key] = int(lib.polus_gemm_auto_split(M, N, K))
     if split_k > 1:
         ws_bytes = lib.polus_gemm_workspace_bytes(M, N, split_k)
         ws = workspace(a.device).get(ws_bytes)

@@ -726,6 +726,61 @@ def test_gemm_pingpong_256wide(ops, tn, M, N, K):
         ops.set_env("POLUS_GEMM_PP")
 
 
+@pytest.mark.parametrize("M,N,K,split", [(4096, 768, 3072, 4), (1024, 768, 2304, 3), (512, 1000, 1024, 2)])
+def test_split_k_with_full_epilogue(ops, M, N, K, split):
+    """bf16 Dense GEMMs that 256-row tiles cannot fill the chip with run their K range in slices (f32 slabs) and a
+    reduce kernel applies the WHOLE epilogue (pgemm::epilogue_tile) to the sum: bias, GELU + pre-activation store,
+    GELU', dropout, residual.  Against the unsplit kernel (same arithmetic except the f32 summation order of the
+    slices: a bf16 ulp at most, on a few elements), against the oracle, and bitwise run to run."""
+    r = rng(M + N + K)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.05
+    bias, R, U = r.standard_normal(N), r.standard_normal((M, N)), r.standard_normal((M, N))
+    dt = torch.bfloat16
+    a_t, b_t, bias_t, r_t, u_t = dev(A, dt), dev(B, dt), dev(bias, torch.float32), dev(R, dt), dev(U, dt)
+    base = rounded(A, dt) @ rounded(B, dt).T
+    tol = TOL[dt]
+
+    def run(sk, **kw):
+        out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+        kw2 = dict(kw)
+        if kw2.get("aux") == "new":
+            kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+        ops.gemm(a_t, b_t, out, split_k=sk, **kw2)
+        return out, kw2.get("aux")
+
+    def both(what, ref, **kw):
+        (o1, x1), (os_, xs), (os2, _) = run(1, **kw), run(split, **kw), run(split, **kw)
+        assert torch.equal(os_, os2), f"{what}: split path is not reproducible"
+        assert_close(host(os_), ref, tol, f"{what} (split) vs oracle")
+        d = (os_.float() - o1.float()).abs()
+        scale = o1.float().abs().clamp_min(2.0 ** -6)
+        assert float((d / scale).max()) <= 2.0 ** -6, f"{what}: split differs from unsplit by more than two bf16 ulps"
+        assert float((d > 0).float().mean()) < 0.2, f"{what}: too many elements differ"
+        return os_, xs
+
+    both("bias", base + bias, bias=bias_t)
+    out, aux = both("gelu", ob.gelu(base + bias), bias=bias_t, aux="new", act="gelu", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(aux), base + bias, tol, "pre-activation (split)")
+    both("bias+resid", base + bias + rounded(R, dt), bias=bias_t, resid=r_t)
+    both("gelu bwd", base * ob.gelu_grad(rounded(U, dt)), aux=u_t, act="gelu", flags=ops.GEMM_ACT_BWD)
+    keep = host(ops.dropout_mask(77, 0.25, M * N)).astype(np.float64).reshape(M, N)
+    both("dropout+resid", (base + bias) * keep / 0.75 + rounded(R, dt), bias=bias_t, resid=r_t, drop_p=0.25, seed=77)
+
+
+def test_gemm_auto_split_heuristic(ops):
+    """polus_gemm_auto_split: 1 where a 256-wide ping-pong tile fills the chip (the headline shapes), where K is short,
+    and where the ring tiles already take a quarter of the slots (8192 tokens: slicing measured slower there);
+    slices where 4096 tokens meet N = 768 (BASELINE configs[1])."""
+    from polus_amd import _lib
+    f = _lib.load().polus_gemm_auto_split
+    assert [f(16384, n, k) for n, k in ((768, 3072), (3072, 768), (2304, 768), (768, 768))] == [1, 1, 1, 1]
+    assert f(4096, 768, 3072) == 4 and f(4096, 768, 2304) == 4 and f(4096, 768, 768) == 1
+    assert f(4096, 3072, 768) == 1 and f(4096, 2304, 768) == 1
+    assert f(8192, 768, 3072) == 1 and f(8192, 768, 2304) == 1
+    assert f(4096, 1024, 4096) == 1 and f(2048, 1024, 4096) == 6
+    assert f(128, 768, 3072) == 1 and f(4096, 64, 3072) == 1 and f(4096, 768, 1000) == 1
+
+
 def test_dropout_mask_definition_and_statistics(ops):
     """The dropout mask is the engine's own counter-based generator (one murmur3-finaliser hash per FOUR elements,
     polus_amd/csrc/common.h).  Pinned here against a numpy restatement at several offsets (aligned and not, and
