@@ -175,16 +175,19 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
     # ---- instrumented step: HIP events (recorded on the launch stream) around every GEMM launch.
     # Every rank takes the step -- it contains the gradient all-reduce -- only rank 0 records.  The dW
     # GEMMs normally run beside the dX GEMMs on a side stream; an event pair would then time two kernels
-    # sharing the CUs, so this one step keeps everything on one stream (as the rocprof summaries under
-    # profiles/ do with POLUS_OVERLAP_DW=0).
+    # sharing the CUs, and the optimizer update normally starts inside backward on a third stream; this one
+    # step keeps everything on one stream (as the rocprof summaries under profiles/ do with POLUS_OVERLAP_DW=0
+    # POLUS_UPDATE_IN_BACKWARD=0).
     roof, rec = None, []
     if rank == 0:
         ops.GEMM_PROFILE = rec
     overlap = getattr(model, "overlap_dw", False)
     model.overlap_dw = False
+    trainer.update_in_backward = False
     one_step(warmup + steps)
     torch.cuda.synchronize()
     model.overlap_dw = overlap
+    trainer.update_in_backward = True
     ops.GEMM_PROFILE = None
     peak = PEAK_TFLOPS[dtype]
     if rank == 0:

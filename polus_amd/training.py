@@ -165,8 +165,9 @@ class BaseTrainer:
         """The in-backward optimizer update (see _UpdateInBackward), when nothing needs all gradients at once: one
         process, one arena on the GPU swept by the fused Adam, no post_process_grads, no global-norm clipping, no
         step graph (its eager warm-up steps must take the path that is captured).  POLUS_UPDATE_IN_BACKWARD=0 keeps
-        the single launch after backward."""
-        if getattr(self, "_graphed", None) is not None:
+        the single launch after backward; `trainer.update_in_backward = False` does the same for the steps that
+        follow (bench.py's instrumented single-stream step)."""
+        if getattr(self, "_graphed", None) is not None or not getattr(self, "update_in_backward", True):
             return None
         key = tuple(id(v) for v in self.trainable_weights)
         u = getattr(self, "_updater_cached", False)
@@ -185,7 +186,7 @@ class BaseTrainer:
         """The per-bucket optimizer update behind each all-reduce (_UpdateBehindAllReduce): all-reduce scheme, GPU
         arena, the fused Adam, nothing that needs every gradient at once.  POLUS_UPDATE_IN_BACKWARD=0 keeps the
         update after backward (split around the last bucket)."""
-        if self._dp_mode() != "allreduce" or reducer.mode == "rs":
+        if self._dp_mode() != "allreduce" or reducer.mode == "rs" or not getattr(self, "update_in_backward", True):
             return None
         key = tuple(id(v) for v in self.trainable_weights)
         u = getattr(self, "_updater_dp_cached", False)
