@@ -334,19 +334,22 @@ static int pp_tile(int M, int N, int K, int mode, bool vec16) {
 }
 
 // Number of K slices a bf16 Dense GEMM (both operands K-contiguous, bf16 C, any epilogue) should be cut into: 1 when a
-// 256-wide ping-pong tile fills the chip or the 256 x 128 ring tiles take a quarter or more of its 2 x #CU slots;
-// otherwise enough slices to bring the ring launch to ~3/4 of the slots, each at least 512 deep (<= 8).  Measured in
-// the step (profiles/r02_ab_auto_split.txt): at 19 % of the slots (4096 tokens, N = 768: 4 slices) the step gains
-// 2 %; at 37 % (8192 tokens: 2 slices) it loses 3 % -- the f32 slabs cost more than the idle CUs.  The caller passes
-// the result as split_k with polus_gemm_workspace_bytes(M, N, split_k) of workspace.
+// 256-wide ping-pong tile fills the chip, when the 256 x 128 ring tiles take more than a quarter of its 2 x #CU slots, or
+// when K < 2048; otherwise enough slices to bring the ring launch to ~3/4 of the slots, each at least 768 deep (<= 8).
+// From tools/split_sweep.py (profiles/r02_split_sweep.txt, residual epilogue, isolated launches): 4096 x 768 x 3072
+// 60.7 -> 44.5 us at 3-4 slices, 4096 x 1024 x 4096 78.0 -> 59.6 us at 3, 2048 x 768 x 3072 59.5 -> 32.9 us at 4;
+// 8192 tokens and K = 1024 are slower sliced (66.5 vs 61.7 us, 32.7 vs 24.7 us).  In the step the slabs cost more than
+// in isolation (profiles/r02_ab_auto_split.txt, step time: 4096 tokens / N = 768 (19 % of the slots) -3.2 %, BERT-large
+// 4096 tokens / N = 1024 (25 %) -1.2 %, 6144 tokens (28 %) +2.5 %, 8192 tokens (37 %) +3 %), hence the quarter.
+// The caller passes the result as split_k with polus_gemm_workspace_bytes(M, N, split_k) of workspace.
 extern "C" int polus_gemm_auto_split(int M, int N, int K) {
-    if (!polus_cfg().gemm_auto_split || M < 256 || N < 128 || K % 64 != 0 || K < 1024) return 1;
+    if (!polus_cfg().gemm_auto_split || M < 256 || N < 128 || K % 64 != 0 || K < 2048) return 1;
     if (pp_tile(M, N, K, 0, true)) return 1;
     const long slots = 2L * polus_num_cus();
     const long t = (long)((M + 255) / 256) * ((N + 127) / 128);
-    if (4 * t >= slots) return 1;
+    if (4 * t > slots) return 1;
     long s = (slots * 3 / 4) / t;
-    if (s > K / 512) s = K / 512;
+    if (s > K / 768) s = K / 768;
     if (s > 8) s = 8;
     return s < 2 ? 1 : (int)s;
 }

@@ -195,9 +195,17 @@ def test_c5_bert_base_s512_grad_accum_x4(mode):
 # ------------------------------------------------------------------------------ configs[3]
 def test_c4_bert_large_dual_encoder_s512():
     """configs[3]: BERT-large (L=24, H=1024) dual encoder, S=512, bf16, through
-    EfficientDenseRetrievalTrainer (polus/ir/training.py:47-117).  The [CLS] state of one query against the
-    oracle (f32 engine 1e-4, bf16 engine 5e-2 of max|ref|); the encoder arena is bit-unchanged by the step
-    (no gradient reaches BERT); the projection gradients of the bf16 engine track the f32 engine's."""
+    EfficientDenseRetrievalTrainer (polus/ir/training.py:47-117).  Per engine: the [CLS] state of one query against
+    the oracle (f32 1e-4, bf16 5e-2 of max|ref|); the encoder arena bit-unchanged by the step (no gradient reaches
+    BERT); the reported loss and the projection gradients against the oracle applied to THAT engine's own [CLS]
+    states (projections -> in-batch scores -> softmax CE on the diagonal).  Across engines: the relative error of
+    the bf16 encoder output.
+
+    What is deliberately not asserted: the gap between the bf16 and the f32 loss.  A random-init BERT-large maps
+    every input to nearly the same [CLS] state, so the 8 x 8 in-batch loss hangs on small differences between them
+    and amplifies the encoder's 1.2e-2 rounding noise: for these very inputs the gap was +0.03, +0.17 and +0.32
+    under three builds whose encoder error is identical (1.23e-2: tools/debug/c4_encoder_err.py) and whose kernels
+    differ only in f32 summation order (LayerNorm kernel, split-K of the N = 1024 GEMMs)."""
     from polus_amd.ir.models import DualEncoder
     from polus_amd.ir.training import ContrastiveLoss, EfficientDenseRetrievalTrainer, InBatchDotScores
     from polus_amd.optimizers import Adam
@@ -208,32 +216,41 @@ def test_c4_bert_large_dual_encoder_s512():
     q = {"input_ids": torch.from_numpy(qi).cuda(), "attention_mask": torch.from_numpy(qm).cuda()}
     d = {"input_ids": torch.from_numpy(di).cuda(), "attention_mask": torch.from_numpy(dm).cuda()}
     ref_cls = ob.bert_fwd(params, ocfg, qi[:1], qm[:1])[1]
-    grads, losses, rel_hidden = {}, {}, {}
+    losses, rel_hidden = {}, {}
     for mode in ("f32", "bf16"):
         enc = build(ocfg, params, None, None, mode, num_labels=None)
         cls = host(enc(**{k: v[:1] for k, v in q.items()}, training=False).pooler_output)
         assert_close(cls, ref_cls, 1e-4 if mode == "f32" else 5e-2, f"[CLS] of query 0 ({mode})")
-        hid = enc(**q, training=False).last_hidden_state.float()
+        out_q = enc(**q, training=False)
+        hid = out_q.last_hidden_state.float().clone()      # the output lives in the model's scratch: copy before the next forward
+        hq = host(out_q.pooler_output).astype(np.float64)
         if mode == "f32":
-            hid32 = hid.clone()
+            hid32 = hid
         rel_hidden[mode] = float((hid - hid32).norm() / hid32.norm())
-        del hid
+        del out_q
+        hd = host(enc(**d, training=False).pooler_output).astype(np.float64)
         model = DualEncoder(enc, projection_dim=E, compute_dtype=mode)
+        w = {v.name: v.numpy().astype(np.float64) for v in model.trainable_weights}
+        n = [v.name for v in model.trainable_weights]
         before = enc.arena.params.clone()
         trainer = EfficientDenseRetrievalTrainer(model, InBatchDotScores(), optimizer=Adam(1e-3), loss=ContrastiveLoss())
         losses[mode] = float(trainer.train_step(q, d))
         torch.cuda.synchronize()
         assert torch.equal(before, enc.arena.params), "the frozen encoder moved"
-        assert not torch.equal(model.arena.grads, torch.zeros_like(model.arena.grads))
-        grads[mode] = {v.name: host(v.grad) for v in model.trainable_weights}
+        got = {v.name: host(v.grad) for v in model.trainable_weights}
+        # oracle on this engine's own [CLS] states
+        wq, bq, wd, bd = (w[k] for k in n)
+        pq, pd_ = hq @ wq.T + bq, hd @ wd.T + bd
+        loss_ref, ds = ol.sparse_softmax_xent_fwd(pq @ pd_.T, np.arange(B))
+        assert abs(losses[mode] - loss_ref) < (1e-4 if mode == "f32" else 5e-2) * max(1.0, abs(loss_ref)), (mode, losses[mode], loss_ref)
+        dq, dd = ds @ pd_, ds.T @ pq
+        tol = 5e-4 if mode == "f32" else 8e-2
+        assert_close(got[n[0]], dq.T @ hq, tol, f"query projection dW ({mode})")
+        assert_close(got[n[1]], dq.sum(0), tol, f"query projection db ({mode})")
+        assert_close(got[n[2]], dd.T @ hd, tol, f"document projection dW ({mode})")
+        # d loss / d (document bias) is zero analytically (every row of softmax - onehot sums to zero): absolute bound
+        assert np.abs(got[n[3]]).max() <= tol * np.abs(dq.sum(0)).max(), (mode, np.abs(got[n[3]]).max(), np.abs(dq.sum(0)).max())
         del trainer, model, enc
         torch.cuda.empty_cache()
-    # The bf16 engine's encoder output carries 1.2e-2 relative rounding noise after 24 layers whichever LayerNorm
-    # kernel runs (tools/debug/c4_encoder_err.py: wave-per-row 1.23e-2, half-wave 1.23e-2, one against the other
-    # 1.16e-2), and the 8 x 8 in-batch loss built on it sat 0.02 .. 0.17 from the f32 loss over three input seeds
-    # x two kernels (tools/debug/c4_loss.py).  The stable quantity is bounded tightly, the loss at 10 %.
     assert rel_hidden["bf16"] < 2e-2, rel_hidden
-    assert abs(losses["f32"] - losses["bf16"]) < 0.1 * max(1.0, abs(losses["f32"])), losses
-    for k, g32 in grads["f32"].items():
-        if g32.size >= 256:
-            assert cosine(grads["bf16"][k], g32) > 0.95, (k, cosine(grads["bf16"][k], g32))
+    print(f"c4 first-step loss: f32 {losses['f32']:.4f}  bf16 {losses['bf16']:.4f} (gap not asserted, see the docstring)")

@@ -768,16 +768,17 @@ def test_split_k_with_full_epilogue(ops, M, N, K, split):
 
 
 def test_gemm_auto_split_heuristic(ops):
-    """polus_gemm_auto_split: 1 where a 256-wide ping-pong tile fills the chip (the headline shapes), where K is short,
-    and where the ring tiles already take a quarter of the slots (8192 tokens: slicing measured slower there);
-    slices where 4096 tokens meet N = 768 (BASELINE configs[1])."""
+    """polus_gemm_auto_split: 1 where a 256-wide ping-pong tile fills the chip (the headline shapes), where K < 2048,
+    and where the ring tiles take more than a quarter of the slots (6144 and 8192 tokens: slicing measured slower there);
+    slices, each at least 768 deep, where a few thousand tokens meet N = 768 / 1024 (BASELINE configs[1] and [3])."""
     from polus_amd import _lib
     f = _lib.load().polus_gemm_auto_split
     assert [f(16384, n, k) for n, k in ((768, 3072), (3072, 768), (2304, 768), (768, 768))] == [1, 1, 1, 1]
-    assert f(4096, 768, 3072) == 4 and f(4096, 768, 2304) == 4 and f(4096, 768, 768) == 1
+    assert f(4096, 768, 3072) == 4 and f(4096, 768, 2304) == 3 and f(4096, 768, 768) == 1
     assert f(4096, 3072, 768) == 1 and f(4096, 2304, 768) == 1
     assert f(8192, 768, 3072) == 1 and f(8192, 768, 2304) == 1
-    assert f(4096, 1024, 4096) == 1 and f(2048, 1024, 4096) == 6
+    assert f(4096, 1024, 4096) == 3 and f(2048, 1024, 4096) == 5 and f(6144, 768, 3072) == 1
+    assert f(4096, 1024, 1024) == 1 and f(8192, 1024, 4096) == 1 and f(2048, 768, 3072) == 4
     assert f(128, 768, 3072) == 1 and f(4096, 64, 3072) == 1 and f(4096, 768, 1000) == 1
 
 
