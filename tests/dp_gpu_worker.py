@@ -38,7 +38,9 @@ def main():
     steps = 3
     epochs = 2 if mode.endswith("_epochs2") else 1     # the second epoch re-broadcasts weights AND optimizer variables from rank 0
     opt = AdamWeightDecay(learning_rate=warmup_scheduler(steps * epochs, 1e-3), weight_decay_rate=0.01)
-    trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy())
+    validate = mode == "allreduce_epochs2"
+    from polus_amd.metrics import Accuracy
+    trainer = ClassifierTrainer(model, opt, SparseCategoricalCrossentropy(), metrics=[Accuracy(4)] if validate else [])
     assert trainer.use_horovod
     accum = 2 if mode.endswith("_accum2") else 1
     trainer.grad_accum_steps = accum
@@ -53,7 +55,32 @@ def main():
     calls = []
     orig = opt.apply_gradients
     opt.apply_gradients = lambda gv, **kw: (calls.append((len(list(gv)) if not isinstance(gv, list) else len(gv), kw)), orig(gv, **kw))[1]
-    trainer.train(batches, epochs=epochs, callbacks=[])
+    callbacks = []
+    if validate:
+        # polus/callbacks.py:218-261 under data parallelism: every rank predicts its own validation shard on the GPU,
+        # hvd.allgather_object collects the (prediction, label) pairs and rank 0 feeds its metrics
+        import torch
+        from polus_amd.callbacks import ValidationDataCallback
+        val = []
+        for s in range(2):
+            ids, mask, tt, labels = synth_batch(ocfg, 4, 16, 4, 900 + s)
+            val.append(({"input_ids": torch.from_numpy(ids[mine]).cuda(), "attention_mask": torch.from_numpy(mask[mine]).cuda(),
+                         "token_type_ids": torch.from_numpy(tt[mine]).cuda()}, torch.from_numpy(labels[mine]).cuda()))
+        vcb = ValidationDataCallback(val, name="val")
+        callbacks = [vcb]
+    trainer.train(batches, epochs=epochs, callbacks=callbacks)
+    if validate:
+        # what the callback reported after the LAST epoch == accuracy over BOTH ranks' shards with the final weights
+        hits = total = 0
+        for x, y in val:
+            pred = model.inference(x)
+            hits += int((pred == y.to(pred.dtype)).sum()); total += y.numel()
+        both = comm.allgather_object((hits, total))
+        expect = sum(h for h, _ in both) / sum(t for _, t in both)
+        if rank == 0:
+            got = vcb.get_metrics()["Accuracy"]
+            assert len(got) == epochs and abs(got[-1] - expect) < 1e-12, (got, expect)
+            assert both[0] != both[1], "the two validation shards should differ"
     assert trainer._dp_mode() == scheme
     steps *= epochs
     if scheme == "allreduce":

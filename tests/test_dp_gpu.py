@@ -3,7 +3,9 @@
 parameters must equal single-process training on the whole batch at LR x 2
 (polus/training.py:90-94 multiplies the LR by the world size; gradients are averaged) -- for both exchange
 schemes (reduce-scatter -> sharded AdamW -> all-gather, and all-reduce), with gradient accumulation, and
-with bf16 gradient transport.  test_native_rccl_plane_world_1 drives every polus_comm_* entry point on a real
+with bf16 gradient transport, over two epochs (the per-epoch re-broadcast of weights and optimizer variables), and
+-- allreduce_epochs2 -- with a ValidationDataCallback whose per-rank GPU predictions travel through
+hvd.allgather_object to rank 0's metric (polus/callbacks.py:218-261).  test_native_rccl_plane_world_1 drives every polus_comm_* entry point on a real
 RCCL communicator (world size 1: the box has one GPU)."""
 import os
 import subprocess
