@@ -25,7 +25,9 @@ final.  Two exchange schemes:
   bucket -- each rank runs AdamW on its slices only (1/N of the optimizer's HBM traffic), then one all-gather
   per bucket returns the updated f32 parameters to everyone.  Half the bytes during backward, but the all-gather
   can only follow the update and nothing hides it (DESIGN.md §5 has the arithmetic behind the default).
-  Optional bf16 transport of the gradients (`POLUS_DP_BF16=1`) halves the reduce-scatter bytes.
+
+Optional bf16 transport of the gradients (`POLUS_DP_BF16=1`, either scheme) halves the bytes on the wire; the sums are
+then rounded to bf16.
 
 The 1/world (and 1/accumulation) factor is folded into the optimizer's gradient scale instead of a
 separate pass."""
@@ -410,8 +412,17 @@ class GradBucketReducer:
     def _launch_one(self, lo, hi):
         view = self.grads[lo:hi]
         if self.mode != "rs":
-            self.launched_bytes += view.numel() * view.element_size()
-            return self.plane.all_reduce_sum(view)
+            if self.transport_dtype is None:
+                self.launched_bytes += view.numel() * view.element_size()
+                return self.plane.all_reduce_sum(view)
+            # bf16 on the wire: cast the bucket, all-reduce the copy (sums rounded to bf16), widen it back
+            from . import ops
+            if self._stage is None:
+                self._stage = torch.empty(self.grads.numel(), dtype=self.transport_dtype, device=self.grads.device)
+            st = self._stage[lo:hi]
+            ops.cast(view, st)
+            self.launched_bytes += st.numel() * st.element_size()
+            return _CastBack(self.plane.all_reduce_sum(st), st, view)
         s = (hi - lo) // self.world
         mine = self.grads[lo + self.rank * s:lo + (self.rank + 1) * s]
         if self.transport_dtype is None:
@@ -469,12 +480,17 @@ class GradBucketReducer:
 
 
 class _CastBack:
-    """wait() of a bf16-transported bucket: after the collective, widen the owned slice into the f32 arena."""
+    """wait() of a bf16-transported bucket: after the collective, widen the reduced (owned) part back into the f32 arena."""
 
     def __init__(self, handle, src, dst):
         self.handle, self.src, self.dst = handle, src, dst
+        self._widened = False
 
     def wait(self):
+        """The first wait() widens on the stream it is called from; later ones (the reducer's finish() after the
+        trainer has already queued the bucket's update behind it) only wait for the collective."""
         from . import ops
         self.handle.wait()
-        ops.cast(self.src, self.dst)
+        if not self._widened:
+            ops.cast(self.src, self.dst)
+            self._widened = True

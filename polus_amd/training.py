@@ -206,7 +206,7 @@ class BaseTrainer:
             import torch
             bucket = int(float(os.environ.get("POLUS_BUCKET_MB", "64")) * (1 << 20))
             mode = self._dp_mode()
-            bf16 = os.environ.get("POLUS_DP_BF16", "0") == "1" and mode == "rs" and arena.grads.is_cuda
+            bf16 = os.environ.get("POLUS_DP_BF16", "0") == "1" and arena.grads.is_cuda
             r = comm.GradBucketReducer(arena.grads, bucket_bytes=bucket, boundaries=[v.offset for v in arena.vars],
                                        mode=mode, transport_dtype=torch.bfloat16 if bf16 else None)
             self._reducers[id(arena)] = r

@@ -13,10 +13,10 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1]
-    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # (rs | allreduce)[_accum2 | _epochs2] | rs_bf16
+    mode = sys.argv[2] if len(sys.argv) > 2 else "rs"             # (rs | allreduce)[_accum2 | _epochs2 | _bf16]
     scheme = "allreduce" if mode.startswith("allreduce") else "rs"
     os.environ["POLUS_DP_MODE"] = scheme
-    if mode == "rs_bf16":
+    if mode.endswith("_bf16"):
         os.environ["POLUS_DP_BF16"] = "1"
     from polus_amd import comm
     from polus_amd.context import PolusContext
