@@ -42,6 +42,7 @@ struct PolusCfg {
     int dw_fused_reduce;   // POLUS_DW_FUSED_REDUCE: 1 (default) one reduce launch per grouped dW
     int ln_bwd_blocks;     // POLUS_LN_BWD_BLOCKS: cap on LayerNorm-backward workgroups (default 512 = all resident at once; 1024 = round-1 grid)
     int ln_fin_single;     // POLUS_LN_FIN_SINGLE: LayerNorm-backward partials up to this many rows are reduced by one finalize launch, more in two stages (default 512)
+    int gemm_ring128;      // POLUS_GEMM_RING128: -1 never, 0 (default) where the heuristic picks it, 1 wherever it applies (bf16 C, K-contiguous operands)
     int gemm_auto_split;   // POLUS_GEMM_AUTO_SPLIT: 1 (default) polus_gemm_auto_split recommends K slices for under-filled bf16 Dense GEMMs; 0 = always 1
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward for S in {64, 128, 256} (bf16)

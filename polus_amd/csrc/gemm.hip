@@ -333,19 +333,35 @@ static int pp_tile(int M, int N, int K, int mode, bool vec16) {
     return best >= 0.70 ? best_tn : 0;
 }
 
-// Number of K slices a bf16 Dense GEMM (both operands K-contiguous, bf16 C, any epilogue) should be cut into: 1 when a
-// 256-wide ping-pong tile fills the chip, when the 256 x 128 ring tiles take more than a quarter of its 2 x #CU slots, or
-// when K < 2048; otherwise enough slices to bring the ring launch to ~3/4 of the slots, each at least 768 deep (<= 8).
-// From tools/split_sweep.py (profiles/r02_split_sweep.txt, residual epilogue, isolated launches): 4096 x 768 x 3072
-// 60.7 -> 44.5 us at 3-4 slices, 4096 x 1024 x 4096 78.0 -> 59.6 us at 3, 2048 x 768 x 3072 59.5 -> 32.9 us at 4;
-// 8192 tokens and K = 1024 are slower sliced (66.5 vs 61.7 us, 32.7 vs 24.7 us).  In the step the slabs cost more than
-// in isolation (profiles/r02_ab_auto_split.txt, step time: 4096 tokens / N = 768 (19 % of the slots) -3.2 %, BERT-large
-// 4096 tokens / N = 1024 (25 %) -1.2 %, 6144 tokens (28 %) +2.5 %, 8192 tokens (37 %) +3 %), hence the quarter.
-// The caller passes the result as split_k with polus_gemm_workspace_bytes(M, N, split_k) of workspace.
+// 128 x 128 ring tile instead of 256 x 128 (bf16 C, both operands K-contiguous, a compile-time epilogue mode).
+// Chosen where the 256 x 128 tiles would take at most 55 % of their 2 x #CU slots (the ping-pong tile has already been
+// ruled out by then): tools/ring128_sweep.py, profiles/r02_ring128_sweep.txt -- 4096 x 768 x 3072: 60.6 -> 40.6 us,
+// 8192 x 768 x 3072: 61.5 -> 49.5 us, 4096 x 1024 x 4096: 77.0 -> 53.6 us, 8192 x 1024 x 4096 (50 %): 81.0 -> 76.3 us.
+static bool use_ring128(int M, int N, int K, int mode) {
+    const int sel = polus_cfg().gemm_ring128;
+    if (sel < 0 || mode < 0 || M < 128 || N < 128) return false;
+    if (sel > 0) return true;
+    const long slots = 2L * polus_num_cus();
+    const long t256 = (long)((M + 255) / 256) * ((N + 127) / 128);
+    return 20 * t256 <= 11 * slots;
+}
+
+// Number of K slices a bf16 Dense GEMM (both operands K-contiguous, bf16 C, any epilogue) should be cut into (f32 slabs
+// + splitk_reduce_epi_kernel).  1 unless even the 128 x 128 ring tiles would take an eighth or less of their 3 x #CU
+// slots (about two thousand tokens at N = 768) and K >= 2048; then enough slices to bring the 256 x 128 slab launch to
+// ~3/4 of its slots, each at least 768 deep (<= 8).  Slicing wins in isolation over a wider range
+// (profiles/r02_split_sweep.txt) but in the step its f32 slabs cost far more (profiles/r02_ab_auto_split.txt: 6144 and
+// 8192 tokens lose 2.5-3 %), and the 128 x 128 tile beats it wherever that tile fills more than an eighth of the chip
+// (profiles/r02_ring128_sweep.txt).  The caller passes the result as split_k with polus_gemm_workspace_bytes(M, N, split_k).
 extern "C" int polus_gemm_auto_split(int M, int N, int K) {
     if (!polus_cfg().gemm_auto_split || M < 256 || N < 128 || K % 64 != 0 || K < 2048) return 1;
     if (pp_tile(M, N, K, 0, true)) return 1;
-    const long slots = 2L * polus_num_cus();
+    const long ncu = polus_num_cus();
+    if (polus_cfg().gemm_ring128 >= 0) {
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        if (8 * t128 > 3 * ncu) return 1;
+    }
+    const long slots = 2 * ncu;
     const long t = (long)((M + 255) / 256) * ((N + 127) / 128);
     if (4 * t > slots) return 1;
     long s = (slots * 3 / 4) / t;
@@ -484,6 +500,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
             if (const int tn = pp_tile(M, N, K, polus_gemm_p_mode(a, 0, 1), a.epi_vec16))
                 return polus_launch_gemm_pp(a, polus_gemm_p_mode(a, 0, 1), 1, tn, st);
             if (use_persistent(M, N, K, polus_gemm_p_mode(a, 0, 1))) return polus_launch_gemm_p(a, polus_gemm_p_mode(a, 0, 1), 1, 192, polus_num_cus(), st);
+            if (use_ring128(M, N, K, polus_gemm_p_mode(a, 0, 1))) return polus_launch_gemm_ring128(a, polus_gemm_p_mode(a, 0, 1), 1, st);
             return polus_launch_gemm_ring_dropout(a, st);
         }
         const bool v = a.a_vec && a.b_vec;
@@ -502,6 +519,8 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
             }
             if (both_kc && use_persistent(M, N, K, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0)))
                 return polus_launch_gemm_p(a, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), 0, 192, polus_num_cus(), st);
+            if (both_kc && c_dtype == POLUS_BF16 && use_ring128(M, N, K, polus_gemm_p_mode(a, 0, 0)))
+                return polus_launch_gemm_ring128(a, polus_gemm_p_mode(a, 0, 0), 0, st);
             return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, a_ks, b_ks, 1, st);
         }
         GemmArgs s = a;              // slabs: plain f32 stores, epilogue applied by the reduce kernel

@@ -368,17 +368,18 @@ template <int WN> struct EpiDbCfg {
     static constexpr int BUF = 16 * RS;
     static constexpr int BYTES = 2 * BUF;
 };
-template <typename TC, int WN, bool DROP, int MODE>
-__device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)[8][WN / 16], int mb, int nb,
+// MT = m-tiles of 16 rows the wave owns (8 in gemm_pp.hip, 4 in the 128 x 128 ring tile).
+template <typename TC, int WN, bool DROP, int MODE, int MT = 8>
+__device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)[MT][WN / 16], int mb, int nb,
                                                  int lane, unsigned char* lds) {
     typedef bf16_t T;
     constexpr int NT = WN / 16, RS = EpiDbCfg<WN>::RS, BUF = EpiDbCfg<WN>::BUF, PASSES = EpiCfg<WN>::PASSES, CPR = 2 * NT;
     constexpr int SLOTS = EpiCfg<WN>::SLOTS;
     const int i = lane & 15, g = lane >> 4;
-    const bool interior = p.epi_vec16 && (mb + 128 <= p.M) && (nb + WN <= p.N);
+    const bool interior = p.epi_vec16 && (mb + 16 * MT <= p.M) && (nb + WN <= p.N);
     if (!interior) {
 #pragma clang loop unroll(full)
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma clang loop unroll(full)
             for (int nt = 0; nt < NT; ++nt)
                 epilogue_tile<T, TC, DROP>(p, acc_take<false>(acc[mt][nt]), mb + mt * 16 + i, nb + nt * 16 + 4 * g, 0);
@@ -403,7 +404,7 @@ __device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)
             for (int r = 0; r < 8; ++r) bv[ps][r] = 0.f;
         }
     }
-    constexpr int DEPTH = 4, NBUF = DEPTH + 1;         // residual / aux rows fetched DEPTH m-tiles ahead (see epilogue_wave)
+    constexpr int DEPTH = MT < 4 ? MT : 4, NBUF = DEPTH + 1;         // residual / aux rows fetched DEPTH m-tiles ahead (see epilogue_wave)
     bf16x8_t pre[NBUF][2][PASSES];
     auto fetch = [&](int mt, bf16x8_t (&dst)[2][PASSES]) {
         const T* base = has_resid ? resid : static_cast<const T*>(aux);
@@ -427,7 +428,7 @@ __device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)
     stage(0);
     stage(1);
 #pragma clang loop unroll(full)
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         f32x4 lo[2][PASSES], hi[2][PASSES];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -437,8 +438,8 @@ __device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)
                 lo[h][ps] = *reinterpret_cast<const f32x4*>(src);
                 hi[h][ps] = *reinterpret_cast<const f32x4*>(src + 16);
             }
-        if (mt + 2 < 8) stage(mt + 2);                 // behind the reads above in the wave's LDS queue: no wait needed
-        if ((has_resid || act_bwd) && mt + DEPTH < 8) fetch(mt + DEPTH, pre[(mt + DEPTH) % NBUF]);
+        if (mt + 2 < MT) stage(mt + 2);                 // behind the reads above in the wave's LDS queue: no wait needed
+        if ((has_resid || act_bwd) && mt + DEPTH < MT) fetch(mt + DEPTH, pre[(mt + DEPTH) % NBUF]);
 #pragma clang loop unroll(full)
         for (int h = 0; h < 2; ++h) {
 #pragma clang loop unroll(full)
@@ -501,6 +502,9 @@ int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st)
 // gemm_ring.hip: same contract, 256x128 tile, two workgroups per CU.
 // a_ks / b_ks: operand stored [K][rows]; splits > 1: blockIdx.y selects [y*k_per_split, ..) and C + y*c_split_stride.
 int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st);
+// gemm_ring.hip: 128 x 128 tile, three workgroups per CU, both operands K-contiguous, bf16 C, mode from polus_gemm_p_mode:
+// for launches whose 256-row tiles would leave most of the chip idle (a few thousand tokens).
+int polus_launch_gemm_ring128(const pgemm::GemmArgs& a, int mode, int drop, hipStream_t st);
 // several dW problems (both operands K-strided, f32 C / slabs, same K and k_per_split) in one launch
 #define POLUS_MAX_GROUP 8
 int polus_launch_gemm_ring_grouped_dw(const pgemm::GemmArgs* probs, int n, const int* splits, hipStream_t st);

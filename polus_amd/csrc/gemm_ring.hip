@@ -314,6 +314,127 @@ int polus_launch_gemm_ring_grouped_dw(const GemmArgs* probs, int n, const int* s
     return POLUS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 tile of the same ring: 4 waves 2(M) x 2(N), 64 x 64 per wave (4 x 4 MFMA tiles, 64 accumulator
+// registers), LDS stage = A 128 rows x 64 B | B 128 rows x 64 B = 16 KiB, ring of 3 = 48 KiB: THREE workgroups per CU.
+// Four LDS-DMA pieces per wave and K-step (A rows 32w.., B rows 32w..), `vmcnt(4)`.  Both operands K-contiguous,
+// bf16 C, compile-time epilogue (pgemm::epilogue_wave_db with 4 m-tiles).  64 FLOP per filled byte against the
+// 256 x 128 tile's 85, so it only pays where that tile leaves most of the chip idle: a few thousand tokens
+// (M / 256 x N / 128 workgroups on 512 slots) -- twice the workgroups on 768 slots.
+namespace r128 {
+constexpr int TM_ = 128, TN_ = 128, A_BYTES_ = TM_ * 64, B_BYTES_ = TN_ * 64, STAGE_ = A_BYTES_ + B_BYTES_, SMEM_ = NSTAGE * STAGE_;
+static_assert(4 * EpiDbCfg<64>::BYTES <= SMEM_, "the C staging buffers of the 4 waves reuse the operand stages");
+}
+template <bool DROP, int MODE>
+__global__ __launch_bounds__(NTHR, 3) void gemm_ring128_kernel(GemmArgs p) {
+    constexpr int TM_ = r128::TM_, TN_ = r128::TN_, A_BYTES_ = r128::A_BYTES_, STAGE_ = r128::STAGE_;
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles_n = (p.N + TN_ - 1) / TN_;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * TM_, n0 = (wg % tiles_n) * TN_;
+    const int K = p.K;
+    const int nk = (K + TK - 1) / TK;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_chunk_ring);
+
+    // per-lane DMA sources: wave w loads A rows 32w..32w+31 and B rows 32w..32w+31 (2 pieces each);
+    // lane l of a piece covers row (l >> 2), LDS chunk (l & 3); same source-side swizzle as the 256-row tile
+    const bf16_t* src[4];
+    int kofs[4];
+    bool rowok[4];
+    int ldsofs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool isA = j < 2;
+        const bf16_t* base = static_cast<const bf16_t*>(isA ? p.A : p.B);
+        const long ld = isA ? p.lda : p.ldb;
+        const int row = 32 * wid + 16 * (j & 1) + (lane >> 2);
+        const int lc = (lane & 3) ^ pi4((row >> 2) & 3);
+        const int gr = (isA ? m0 : n0) + row;
+        rowok[j] = gr < (isA ? p.M : p.N);
+        kofs[j] = lc * 8;
+        src[j] = base + (long)gr * ld + lc * 8;
+        ldsofs[j] = (isA ? 0 : A_BYTES_) + (32 * wid + 16 * (j & 1)) * 64;
+    }
+    auto issue = [&](int stage, int k0) {
+        unsigned char* st = smem + stage * STAGE_;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t* sp = (rowok[j] && k0 + kofs[j] < K) ? src[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (lds_void_t*)(st + ldsofs[j]), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fc = (g ^ pi4((i >> 2) & 3)) * 16;
+    const int a_off = (wm * 64 + i) * 64 + fc;                // + mt * 1024
+    const int b_off = A_BYTES_ + (wn * 64 + i) * 64 + fc;      // + nt * 1024
+
+    issue(0, 0);
+    if (nk > 1) { issue(1, TK); POLUS_VMCNT(4); } else { POLUS_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();
+
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* st = smem + stage * STAGE_;
+        const bool dma = t + 2 < nk;
+        if (dma) issue(stage == 0 ? 2 : stage - 1, (t + 2) * TK);     // the stage read in step t-1
+        Frag<bf16_t> af[4], bfr[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bfr[nt].v = *reinterpret_cast<const bf16x8*>(st + b_off + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt].v = *reinterpret_cast<const bf16x8*>(st + a_off + mt * 1024);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) mma16(acc[mt][nt], bfr[nt], af[mt]);
+        __builtin_amdgcn_s_setprio(0);
+        if (t + 1 < nk) {
+            if (dma) POLUS_VMCNT(4); else POLUS_VMCNT(0);             // tile t+1 landed
+            POLUS_LGKMCNT0();
+            __builtin_amdgcn_s_barrier();
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    // every wave is done with the operand stages and no DMA is in flight: LDS now stages C
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_wave_db<bf16_t, 64, DROP, MODE, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, smem + wid * EpiDbCfg<64>::BYTES);
+}
+
+template <bool DROP, int MODE>
+int launch_ring128(const GemmArgs& a, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_ring128_kernel<DROP, MODE>;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, r128::SMEM_));
+        attr_done = true;
+    }
+    const int tiles = ((a.M + r128::TM_ - 1) / r128::TM_) * ((a.N + r128::TN_ - 1) / r128::TN_);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), r128::SMEM_, st, a);
+    POLUS_CHECK_LAUNCH("polus_gemm(ring 128 x 128)");
+    return POLUS_OK;
+}
+
+int polus_launch_gemm_ring128(const GemmArgs& a, int mode, int drop, hipStream_t st) {
+    switch (mode) {
+        case 0: return launch_ring128<false, 0>(a, st);
+        case 1: return launch_ring128<false, 1>(a, st);
+        case 2: return drop ? launch_ring128<true, 2>(a, st) : launch_ring128<false, 2>(a, st);
+        case 3: return launch_ring128<false, 3>(a, st);
+    }
+    return POLUS_ERR_INVALID;
+}
+
 int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
     if (polus_gemm_p_mode(a, 0, 1) == 2 && !polus_cfg().ring_runtime_epi) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
     return launch_ring<bf16_t, false, false, true>(a, 1, st);

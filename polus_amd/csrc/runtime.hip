@@ -32,6 +32,7 @@ static void read_cfg() {
     g_cfg.attn_fused = env_int("POLUS_ATTN_FUSED", 1);
     g_cfg.ln_halfwave = env_int("POLUS_LN_HALFWAVE", 1);
     g_cfg.gemm_auto_split = env_int("POLUS_GEMM_AUTO_SPLIT", 1);
+    g_cfg.gemm_ring128 = env_int("POLUS_GEMM_RING128", 0);
     g_cfg.ln_bwd_blocks = env_int("POLUS_LN_BWD_BLOCKS", 512);
     g_cfg.ln_fin_single = env_int("POLUS_LN_FIN_SINGLE", 512);
     g_cfg_ready = true;

@@ -768,18 +768,66 @@ def test_split_k_with_full_epilogue(ops, M, N, K, split):
 
 
 def test_gemm_auto_split_heuristic(ops):
-    """polus_gemm_auto_split: 1 where a 256-wide ping-pong tile fills the chip (the headline shapes), where K < 2048,
-    and where the ring tiles take more than a quarter of the slots (6144 and 8192 tokens: slicing measured slower there);
-    slices, each at least 768 deep, where a few thousand tokens meet N = 768 / 1024 (BASELINE configs[1] and [3])."""
+    """polus_gemm_auto_split: 1 where a 256-wide ping-pong tile fills the chip (the headline shapes), where K < 2048, and
+    wherever the 128 x 128 ring tile fills more than an eighth of its slots (it beats slicing there and writes no
+    slabs); slices, each at least 768 deep, only for about two thousand tokens and fewer."""
     from polus_amd import _lib
     f = _lib.load().polus_gemm_auto_split
     assert [f(16384, n, k) for n, k in ((768, 3072), (3072, 768), (2304, 768), (768, 768))] == [1, 1, 1, 1]
-    assert f(4096, 768, 3072) == 4 and f(4096, 768, 2304) == 3 and f(4096, 768, 768) == 1
-    assert f(4096, 3072, 768) == 1 and f(4096, 2304, 768) == 1
-    assert f(8192, 768, 3072) == 1 and f(8192, 768, 2304) == 1
-    assert f(4096, 1024, 4096) == 3 and f(2048, 1024, 4096) == 5 and f(6144, 768, 3072) == 1
-    assert f(4096, 1024, 1024) == 1 and f(8192, 1024, 4096) == 1 and f(2048, 768, 3072) == 4
-    assert f(128, 768, 3072) == 1 and f(4096, 64, 3072) == 1 and f(4096, 768, 1000) == 1
+    assert f(4096, 768, 3072) == 1 and f(4096, 768, 2304) == 1 and f(8192, 768, 3072) == 1 and f(4096, 1024, 4096) == 1
+    assert f(2048, 768, 3072) == 4 and f(2048, 768, 2304) == 3 and f(1024, 1024, 4096) == 5
+    assert f(2048, 768, 768) == 1 and f(2048, 768, 1000) == 1 and f(128, 768, 3072) == 1 and f(4096, 64, 3072) == 1
+    try:
+        ops.set_env("POLUS_GEMM_RING128", -1)        # without the 128-row tile: the rule measured in the step before it existed
+        assert f(4096, 768, 3072) == 4 and f(4096, 768, 2304) == 3 and f(4096, 1024, 4096) == 3
+        assert f(6144, 768, 3072) == 1 and f(8192, 768, 3072) == 1
+    finally:
+        ops.set_env("POLUS_GEMM_RING128")
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 2304), (1000, 1000, 1056), (384, 256, 96), (8192, 768, 768)])
+def test_gemm_ring128_equals_ring256(ops, M, N, K):
+    """The 128 x 128 ring tile (three workgroups per CU; chosen where 256-row tiles would leave most of the chip idle)
+    against the 256 x 128 ring tile: same MFMA k order, same epilogue arithmetic -> bit-identical C (and pre-activation)
+    in every epilogue mode, ragged edges included; and against the oracle."""
+    r = rng(M + 3 * N + K)
+    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.05
+    bias, R, U = r.standard_normal(N), r.standard_normal((M, N)), r.standard_normal((M, N))
+    dt = torch.bfloat16
+    a_t, b_t, bias_t, r_t, u_t = dev(A, dt), dev(B, dt), dev(bias, torch.float32), dev(R, dt), dev(U, dt)
+    base = rounded(A, dt) @ rounded(B, dt).T
+    tol = TOL[dt]
+
+    def both(**kw):
+        outs = []
+        try:
+            ops.set_env("POLUS_GEMM_PP", -1)
+            for sel in (1, -1):
+                ops.set_env("POLUS_GEMM_RING128", sel)
+                out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+                kw2 = dict(kw)
+                if kw2.get("aux") == "new":
+                    kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+                ops.gemm(a_t, b_t, out, split_k=1, **kw2)
+                outs.append((out, kw2.get("aux")))
+        finally:
+            ops.set_env("POLUS_GEMM_RING128"); ops.set_env("POLUS_GEMM_PP")
+        assert torch.equal(outs[0][0], outs[1][0]), "128-row ring tile differs from the 256-row one"
+        if kw.get("aux") == "new":
+            assert torch.equal(outs[0][1], outs[1][1]), "128-row ring tile: pre-activation differs"
+        return outs[0]
+
+    out, _ = both(bias=bias_t)
+    assert_close(host(out), base + bias, tol, "bias")
+    out, aux = both(bias=bias_t, aux="new", act="gelu", flags=ops.GEMM_ACT_FWD)
+    assert_close(host(aux), base + bias, tol, "aux"); assert_close(host(out), ob.gelu(base + bias), tol, "gelu")
+    out, _ = both(bias=bias_t, resid=r_t)
+    assert_close(host(out), base + bias + rounded(R, dt), tol, "bias+resid")
+    out, _ = both(aux=u_t, act="gelu", flags=ops.GEMM_ACT_BWD)
+    assert_close(host(out), base * ob.gelu_grad(rounded(U, dt)), tol, "gelu bwd")
+    out, _ = both(bias=bias_t, resid=r_t, drop_p=0.25, seed=321)
+    keep = host(ops.dropout_mask(321, 0.25, M * N)).astype(np.float64).reshape(M, N)
+    assert_close(host(out), (base + bias) * keep / 0.75 + rounded(R, dt), tol, "dropout+resid")
 
 
 def test_dropout_mask_definition_and_statistics(ops):
