@@ -23,16 +23,17 @@ def graph_time(fn, n=20, reps=5):
             best = min(best, e0.elapsed_time(e1) / n * 1e-3)
     return best
 
-splits = (1, 2, 3, 4, 6)
-print(f"{'M':>6s} {'N':>5s} {'K':>5s} {'auto':>5s}  " + "  ".join(f"{'s=' + str(s):>9s}" for s in splits))
-for M, N, K in ((4096, 768, 3072), (4096, 768, 2304), (2048, 768, 3072), (8192, 768, 3072), (6144, 768, 3072),
-                (4096, 1024, 4096), (4096, 1024, 1024), (8192, 1024, 4096), (2048, 1024, 4096)):
-    a, b, r = rnd(M, K), rnd(N, K) * 0.05, rnd(M, N)
-    bias = torch.zeros(N, device=dev)
-    c = torch.empty(M, N, dtype=dt, device=dev)
-    cells = []
-    for s in splits:
-        t = graph_time(lambda: ops.gemm(a, b, c, bias=bias, resid=r, split_k=s))
-        cells.append(f"{t*1e6:7.1f}us")
-    auto = _lib.load().polus_gemm_auto_split(M, N, K)
-    print(f"{M:6d} {N:5d} {K:5d} {auto:5d}  " + "  ".join(f"{x:>9s}" for x in cells), flush=True)
+if __name__ == "__main__":
+    splits = (1, 2, 3, 4, 6)
+    print(f"{'M':>6s} {'N':>5s} {'K':>5s} {'auto':>5s}  " + "  ".join(f"{'s=' + str(s):>9s}" for s in splits))
+    for M, N, K in ((4096, 768, 3072), (4096, 768, 2304), (2048, 768, 3072), (8192, 768, 3072), (6144, 768, 3072),
+                    (4096, 1024, 4096), (4096, 1024, 1024), (8192, 1024, 4096), (2048, 1024, 4096)):
+        a, b, r = rnd(M, K), rnd(N, K) * 0.05, rnd(M, N)
+        bias = torch.zeros(N, device=dev)
+        c = torch.empty(M, N, dtype=dt, device=dev)
+        cells = []
+        for s in splits:
+            t = graph_time(lambda: ops.gemm(a, b, c, bias=bias, resid=r, split_k=s))
+            cells.append(f"{t*1e6:7.1f}us")
+        auto = _lib.load().polus_gemm_auto_split(M, N, K)
+        print(f"{M:6d} {N:5d} {K:5d} {auto:5d}  " + "  ".join(f"{x:>9s}" for x in cells), flush=True)
