@@ -78,7 +78,8 @@ int polus_set_dynamic_params(const void* dev_block16);
  * applies the whole epilogue (residual, activation forward / backward, dropout); otherwise only
  * bias / ACCUM_C epilogues are allowed with split_k > 1.
  * polus_gemm_auto_split: the number of K slices the library recommends for a bf16 Dense GEMM of this size
- * (1 = none): > 1 when 256-row tiles would fill less than half of the chip (a few thousand tokens, N = 768). */
+ * (1 = none; a tuning query with no counterpart in the reference, whose Dense layers are Keras / HF calls):
+ * > 1 only for about two thousand tokens and fewer, where even its 128 x 128 tile leaves most of the chip idle. */
 size_t polus_gemm_workspace_bytes(int M, int N, int split_k);
 int polus_gemm_auto_split(int M, int N, int K);
 int polus_gemm(int dtype, int a_layout, int b_layout, int c_dtype,
