@@ -181,6 +181,26 @@ class ParamArena:
         elif var.matrix and len(var.shape) == 2:
             ops.transpose_bf16(var.compute, var.compute_t)
 
+    def refresh_transposed_of(self, variables):
+        """The transposed shadows of just these variables, in one launch: the in-backward optimizer update
+        re-derives a window's right after updating it, instead of one launch for the whole arena after backward."""
+        if self.shadow_t is None:
+            return
+        mats = [v for v in variables if v.matrix and len(v.shape) == 2]
+        if not mats:
+            return
+        from . import ops
+        cache = self.__dict__.setdefault("_tr_sub", {})
+        key = tuple(id(v) for v in mats)
+        t = cache.get(key)
+        if t is None:
+            segs, t0 = [], 0
+            for v in mats:
+                segs.append((v.offset, v.shape[0], v.shape[1], t0))
+                t0 += ((v.shape[0] + 63) // 64) * ((v.shape[1] + 63) // 64)
+            t = cache[key] = (torch.tensor(segs, dtype=torch.int64).to(self.device), t0)
+        ops.transpose_bf16_batched(self.shadow, self.shadow_t, t[0], t[0].shape[0], t[1])
+
     def refresh_shadow(self, var=None):
         if self.shadow is None:
             return

@@ -21,8 +21,8 @@ class _UpdateInBackward:
     window final (`model.grad_ready_hook`), on its own stream, beside the backward pass of the layers below -- the
     update is HBM-bound, backward mostly MFMA-bound.  Same kernel, same arithmetic per parameter as the one launch
     of `optimizer.apply_gradients` after backward (polus/training.py:191): the parameters come out bit-identical
-    (tests/test_boundary_gpu.py).  The transposed shadows of the GEMM weights are re-derived once, at the end; the
-    main stream joins before `train_step` returns."""
+    (tests/test_boundary_gpu.py).  The transposed shadows of a window's GEMM weights are re-derived right behind its
+    update; the main stream joins before `train_step` returns."""
 
     def __init__(self, trainer, arena):
         import torch
@@ -42,6 +42,7 @@ class _UpdateInBackward:
         self.stream.wait_event(self.fork)
         with _lib.stream_scope(self.stream):
             self.trainer.optimizer.apply_gradients([(v.grad, v) for v in vs], _advance=self.first, _refresh=False)
+            self.arena.refresh_transposed_of(vs)     # the dX GEMMs that read these W^T completed before the fork event
         self.first = False
         for v in vs:
             del self.left[id(v)]
@@ -57,7 +58,6 @@ class _UpdateInBackward:
         if self.left:                        # windows backward never reported (a model without the hook calls)
             self._apply(list(self.left.values()))
         with _lib.stream_scope(self.stream):
-            self.arena.refresh_transposed()
             self.done.record(self.stream)
         torch.cuda.current_stream().wait_event(self.done)
 
@@ -77,6 +77,7 @@ class _UpdateBehindAllReduce(_UpdateInBackward):
             work.wait()                      # the update stream (not the compute stream) waits for this bucket
             if vs:
                 self.trainer.optimizer.apply_gradients([(v.grad, v) for v in vs], _advance=self.first, _refresh=False)
+                self.arena.refresh_transposed_of(vs)
                 self.first = False
         for v in vs:
             del self.left[id(v)]
