@@ -260,3 +260,61 @@ def test_mock_comm_surface_world_size_one():
     tape = object()
     assert comm.DistributedGradientTape(tape) is tape
     assert comm.init() in ("mock", "gloo", "nccl")
+
+
+def test_in_backward_update_gating_and_state_sync_on_the_host():
+    """The optional step schedules fall back cleanly where they do not apply: no in-backward optimizer update for an
+    arena that is not on the GPU or an optimizer that is not the fused Adam (the single launch after backward stays);
+    trainer.sync_optimizer_state() is a no-op in a single process; save_training_state refuses Adam moments that a
+    data-parallel reduce-scatter step left current on this rank's slices only."""
+    from polus_amd.checkpoint import save_training_state
+    model = FakeLinearModel(seed=3)
+    trainer = ClassifierTrainer(model, FakeSGD(0.1), FakeXent())
+    assert not trainer.use_horovod
+    assert trainer._updater() is None                     # CPU arena, SGD test double
+    trainer.update_in_backward = False
+    assert trainer._updater() is None
+    trainer.update_in_backward = True
+    x, y = make_data(1)[0]
+    before = model.arena.params.clone()
+    trainer.train_step(x, y)                              # takes the plain path: one apply_gradients after backward
+    assert not torch.equal(before, model.arena.params) and model.grad_ready_hook is None
+    trainer.sync_optimizer_state()                        # nothing to gather in one process
+    assert getattr(trainer, "_opt_state_synced", True)
+    # the guard of the resume state: a (simulated) data-parallel trainer whose moments are sharded
+    trainer.use_horovod, trainer._opt_state_synced = True, False
+    with pytest.raises(RuntimeError, match="sync_optimizer_state"):
+        save_training_state(trainer, "/nonexistent/never-written")
+    trainer.use_horovod, trainer._opt_state_synced = False, True
+
+
+def test_gemm_split_auto_is_declared_and_bucket_callback_fires_in_launch_order():
+    """polus_gemm_auto_split is part of the C ABI the host binds; GradBucketReducer.on_launched hands every bucket,
+    in launch (descending-offset) order, to the trainer that queues the bucket's update behind it."""
+    from polus_amd import _lib
+    assert "polus_gemm_auto_split" in _lib.SIGNATURES
+    g = torch.arange(1000, dtype=torch.float32)
+    r = comm.GradBucketReducer(g, bucket_bytes=4 * 300, boundaries=[0, 100, 250, 600, 900], plane=_EchoPlane())
+    seen = []
+    r.on_launched = lambda lo, hi, work: seen.append((lo, hi, work))
+    r.begin()
+    r.on_ready(900, 1000)
+    assert [(lo, hi) for lo, hi, _ in seen] == [(900, 1000)]
+    r.on_ready(250, 900)
+    r.finish()
+    assert [(lo, hi) for lo, hi, _ in seen] == list(r.buckets) and seen[0][0] > seen[-1][0]
+    assert all(w.waited >= 1 for _, _, w in seen)         # finish() waited for every bucket
+
+
+class _EchoWork:
+    def __init__(self):
+        self.waited = 0
+
+    def wait(self):
+        self.waited += 1
+
+
+class _EchoPlane:
+    """A data plane that reduces nothing (world size 1): records the calls."""
+    def all_reduce_sum(self, t):
+        return _EchoWork()
