@@ -223,9 +223,11 @@ int polus_argmax(const float* x, long ldx, int32_t* out, int rows, int C, void* 
 
 /* ---- confusion matrix of the validation path (polus/metrics.py:51-66, tf.math.confusion_matrix):
  * cm[row_idx[i]][col_idx[i]] += 1 for i < n; cm is int32 [C, C] on the device and is ACCUMULATED into
- * (zero it to start); indices outside [0, C) are ignored; C <= 128.  Integer atomics: exact. */
+ * (zero it to start); C <= 128.  Integer atomics: exact.  A pair with an index outside [0, C) adds nothing to cm
+ * and 1 to *rejected (device int32, accumulated; may be null): tf.math.confusion_matrix raises on such input, the
+ * caller decides (polus_amd/metrics.py raises in evaluate()). */
 int polus_confusion_matrix(const int32_t* row_idx, const int32_t* col_idx, int64_t n, int C,
-                           int32_t* cm, void* stream);
+                           int32_t* cm, int32_t* rejected, void* stream);
 
 /* ---- optimizer (optimizer.apply_gradients, polus/training.py:191): Keras Adam /
  * HF AdamWeightDecay over a flat f32 arena.  `seg` is a device table of int64 triples
@@ -280,6 +282,9 @@ int polus_scale(float* x, float a, int64_t n, void* stream);
 int polus_comm_unique_id(void* out_id128);
 int polus_comm_init(void** comm, int rank, int world, const void* unique_id128);
 int polus_comm_destroy(void* comm);
+/* what RCCL itself says about the communicator: ranks it spans, this rank, the HIP device it is bound to
+ * (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) -- bench.py prints n_ranks as `rccl_ranks` */
+int polus_comm_info(void* comm, int* n_ranks, int* rank, int* device);
 int polus_comm_broadcast(void* comm, void* buf, size_t bytes, int root, void* stream);
 int polus_comm_allreduce_sum(void* comm, void* buf, size_t count, int dtype, void* stream);
 int polus_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, size_t recv_count, int dtype, void* stream);

@@ -54,7 +54,7 @@ SIGNATURES = {
     "polus_crf_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_crf_nll": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "polus_crf_viterbi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "polus_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "polus_confusion_matrix": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
     "polus_argmax": (_i, [_vp, _l, _vp, _i, _i, _vp]),
     "polus_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64,
                              _f, _f, _f, _f, _f, _f, _f, _vp, _vp]),
@@ -72,6 +72,7 @@ SIGNATURES = {
     "polus_comm_unique_id": (_i, [_vp]),
     "polus_comm_init": (_i, [_c.POINTER(_vp), _i, _i, _vp]),
     "polus_comm_destroy": (_i, [_vp]),
+    "polus_comm_info": (_i, [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "polus_comm_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
     "polus_comm_allreduce_sum": (_i, [_vp, _vp, _sz, _i, _vp]),
     "polus_comm_reduce_scatter_sum": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

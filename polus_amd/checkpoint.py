@@ -100,12 +100,13 @@ def save_training_state(trainer, path):
            "step_counter": np.int64(trainer.step_counter), "micro": np.int64(getattr(trainer, "step_counter_micro", 0)),
            "dropout_step": np.int64(getattr(trainer.model, "dropout_step", 0))}
     for i, a in enumerate(arenas):
-        out[f"a{i}.params"] = a.params.detach().cpu().numpy()
+        n = getattr(a, "extent", a.params.numel())       # the padding behind the last variable is not state
+        out[f"a{i}.params"] = a.params[:n].detach().cpu().numpy()
         if hasattr(opt, "_slots"):
             m, v = opt._slots(a)
-            out[f"a{i}.m"], out[f"a{i}.v"] = m.detach().cpu().numpy(), v.detach().cpu().numpy()
+            out[f"a{i}.m"], out[f"a{i}.v"] = m[:n].detach().cpu().numpy(), v[:n].detach().cpu().numpy()
         if getattr(trainer, "grad_accum_steps", 1) > 1:
-            out[f"a{i}.grads"] = a.grads.detach().cpu().numpy()      # a partially accumulated step
+            out[f"a{i}.grads"] = a.grads[:n].detach().cpu().numpy()      # a partially accumulated step
     p = path if path.endswith(".state.npz") else path + ".state.npz"
     np.savez(p, **out)
     return p
@@ -122,16 +123,22 @@ def load_training_state(trainer, path):
     opt = trainer.optimizer
     for i, a in enumerate(arenas):
         w = z[f"a{i}.params"]
-        if w.shape[0] != a.params.numel():
-            raise ValueError(f"{p}: arena {i} holds {w.shape[0]} parameters, the model has {a.params.numel()}")
-        a.params.copy_(torch.from_numpy(w))
+        n = getattr(a, "extent", a.params.numel())
+        if w.shape[0] < n or w.shape[0] > a.params.numel() and np.any(w[a.params.numel():]):
+            raise ValueError(f"{p}: arena {i} holds {w.shape[0]} parameters, the model has {n}")
+        n = min(w.shape[0], a.params.numel())            # files of earlier versions carry their (zero) padding
+
+        def put(dst, src):
+            dst[:n].copy_(torch.from_numpy(src[:n]))
+            dst[n:].zero_()
+        put(a.params, w)
         a.refresh_shadow()
         if f"a{i}.m" in z.files and hasattr(opt, "_slots"):
             m, v = opt._slots(a)
-            m.copy_(torch.from_numpy(z[f"a{i}.m"]))
-            v.copy_(torch.from_numpy(z[f"a{i}.v"]))
+            put(m, z[f"a{i}.m"])
+            put(v, z[f"a{i}.v"])
         if f"a{i}.grads" in z.files:
-            a.grads.copy_(torch.from_numpy(z[f"a{i}.grads"]))
+            put(a.grads, z[f"a{i}.grads"])
     if hasattr(opt, "iterations"):
         opt.iterations = int(z["iterations"])
     trainer.step_counter = int(z["step_counter"])

@@ -6,11 +6,13 @@ polus/callbacks.py:249).  Two planes:
 
 * control plane (host objects, barriers, the 128-byte RCCL id): a `gloo` process group over the
   torchrun rendezvous -- plumbing;
-* data plane (gradients, parameters): the `polus_comm_*` entry points of libpolus_hip.so over RCCL
-  (include/polus_hip.h), queued on a side HIP stream and fenced against the compute stream with events.
-  `POLUS_DIST_BACKEND=nccl` swaps in torch.distributed's own RCCL binding, `gloo` the CPU transport (the
-  multi-process tests, and several ranks sharing one GPU -- RCCL refuses duplicate devices).  If the native
-  communicator cannot be brought up on some rank, every rank falls back to the torch binding together.
+* data plane (gradients, parameters): RCCL.  By default through torch.distributed's binding (`nccl`);
+  `POLUS_DIST_BACKEND=native` selects the `polus_comm_*` entry points of libpolus_hip.so (include/polus_hip.h: the
+  same RCCL collectives through the C ABI, queued on a side HIP stream and fenced against the compute stream with
+  events) -- opt-in until a multi-GPU run has pinned it; if it cannot be brought up on some rank, every rank falls
+  back to the torch binding together (the ranks vote over the control plane before any of them enters
+  ncclCommInitRank).  `gloo` is the CPU transport (the multi-process tests, and several ranks sharing one GPU --
+  RCCL refuses duplicate devices).
 
 Horovod's DistributedGradientTape averages every gradient tensor with one all-reduce per tensor fused
 by a background thread.  Here the gradients already live in one flat f32 arena laid out in forward
@@ -114,32 +116,42 @@ class _NativePlane:
     name = "native"
 
     def __init__(self, world, rk):
-        from . import _lib
-        # the RCCL copy that shares torch's HIP runtime (same SONAME as /opt/rocm's)
-        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        if os.path.exists(bundled):
-            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
-        self.lib = _lib.load()
-        self.check = _lib.check
-        # Every rank reaches every control-plane collective below whatever failed locally: a rank that raised
-        # early would leave the others blocked in a broadcast or inside ncclCommInitRank.
-        uid, err = (ctypes.c_ubyte * 128)(), None
-        if rk == 0:
-            try:
+        # Every rank reaches every control-plane collective below whatever failed locally, and the ranks vote BEFORE
+        # any of them enters ncclCommInitRank: a rank that raised early (library missing, symbol missing, no unique
+        # id) would otherwise leave its peers blocked inside the RCCL bootstrap, which has no timeout.
+        err, uid = None, (ctypes.c_ubyte * 128)()
+        try:
+            from . import _lib
+            # the RCCL copy that shares torch's HIP runtime (same SONAME as /opt/rocm's)
+            bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(bundled):
+                ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+            self.lib = _lib.load()
+            self.check = _lib.check
+            self.check(self.lib.polus_comm_group_start(), "polus_comm_group_start")     # dlopen + every RCCL symbol
+            self.check(self.lib.polus_comm_group_end(), "polus_comm_group_end")
+            if rk == 0:
                 self.check(self.lib.polus_comm_unique_id(uid), "polus_comm_unique_id")
-            except Exception as e:      # noqa: BLE001
-                err = e
-        box = [bytes(uid) if err is None else None]
+        except Exception as e:      # noqa: BLE001
+            err = e
+        box = [bytes(uid) if (rk == 0 and err is None) else None]
         dist.broadcast_object_list(box, src=0)            # control plane (gloo)
         ready = [None] * world
-        dist.all_gather_object(ready, box[0] is not None)
+        dist.all_gather_object(ready, err is None and box[0] is not None)
         if not all(ready):
-            raise RuntimeError(f"polus_comm_unique_id failed on rank 0: {err}")
+            raise RuntimeError(f"native RCCL plane: local bring-up failed on rank(s) {[r for r, ok in enumerate(ready) if not ok]}"
+                               + (f" ({err})" if err is not None else ""))
         uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
         self.comm = ctypes.c_void_p()
         self.check(self.lib.polus_comm_init(ctypes.byref(self.comm), rk, world, uid), "polus_comm_init")
         self.stream = torch.cuda.Stream()
         self.world, self.rank = world, rk
+
+    def info(self):
+        """(ranks, rank, device) as RCCL reports them for this communicator."""
+        n, r, d = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.check(self.lib.polus_comm_info(self.comm, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)), "polus_comm_info")
+        return n.value, r.value, d.value
 
     def _enter(self):
         ev = torch.cuda.Event()
@@ -227,7 +239,11 @@ def init():
         return "mock"
     rk, local_rank = _env_int("RANK", 0), _env_int("LOCAL_RANK", 0)
     use_gpu = torch.cuda.is_available()
-    backend = os.environ.get("POLUS_DIST_BACKEND") or ("native" if use_gpu else "gloo")
+    # Data plane on GPUs: torch.distributed's RCCL binding by default.  The native plane (polus_comm_* through the C ABI,
+    # POLUS_DIST_BACKEND=native) issues the same RCCL collectives on a stream of ours; it has been driven end to end on
+    # a communicator of size 1 only (no multi-GPU box in the build environment), so it stays opt-in until a run on
+    # >= 2 GPUs has recorded parity and timing for it -- "multi-GPU parity unpinned", DESIGN.md section 5.
+    backend = os.environ.get("POLUS_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if use_gpu:
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -282,6 +298,30 @@ def is_distributed():
 
 def data_plane():
     return _STATE["plane"]
+
+
+def data_plane_info():
+    """What the data plane itself reports (a collective: every rank calls it): the sum of a one-per-rank all-reduce
+    pushed through the plane -- the number of ranks the gradient exchange really spans -- and, on the native plane,
+    RCCL's own ncclCommCount / ncclCommUserRank / ncclCommCuDevice.  bench.py prints it as `rccl_ranks`."""
+    out = {"data_plane": _STATE["backend"] or "none", "world": size(), "ranks_seen": 1}
+    plane = data_plane()
+    if plane is None:
+        return out
+    dev = "cuda" if (torch.cuda.is_available() and _STATE["backend"] != "gloo") else None
+    if dev is None and torch.cuda.is_available():
+        dev = "cuda"
+    probe = torch.ones(64, dtype=torch.float32, device=dev or "cpu")
+    w = plane.all_reduce_sum(probe)
+    if w is not None:
+        w.wait()
+    if probe.is_cuda:
+        torch.cuda.synchronize()
+    out["ranks_seen"] = int(round(float(probe[0].item())))
+    if isinstance(plane, _NativePlane):
+        n, r, d = plane.info()
+        out.update(rccl_comm_count=n, rccl_comm_rank=r, rccl_comm_device=d)
+    return out
 
 
 def DistributedGradientTape(tape):

@@ -23,6 +23,9 @@ struct Rccl {
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -46,6 +49,9 @@ int rccl_load() {
     POLUS_SYM(Broadcast, "ncclBroadcast");
     POLUS_SYM(ReduceScatter, "ncclReduceScatter");
     POLUS_SYM(AllGather, "ncclAllGather");
+    POLUS_SYM(CommCount, "ncclCommCount");
+    POLUS_SYM(CommUserRank, "ncclCommUserRank");
+    POLUS_SYM(CommCuDevice, "ncclCommCuDevice");
     POLUS_SYM(GroupStart, "ncclGroupStart");
     POLUS_SYM(GroupEnd, "ncclGroupEnd");
     POLUS_SYM(GetErrorString, "ncclGetErrorString");
@@ -98,6 +104,15 @@ extern "C" int polus_comm_destroy(void* comm) {
     ncclResult_t r = g_rccl.CommDestroy(c->comm);
     delete c;
     if (r != ncclSuccess) { polus_set_error("ncclCommDestroy: %s", g_rccl.GetErrorString(r)); return POLUS_ERR_HIP; }
+    return POLUS_OK;
+}
+
+extern "C" int polus_comm_info(void* comm, int* n_ranks, int* rank, int* device) {
+    POLUS_REQUIRE(comm && n_ranks && rank && device, "polus_comm_info: null pointer");
+    PolusComm* c = static_cast<PolusComm*>(comm);
+    POLUS_NCCL(g_rccl.CommCount(c->comm, n_ranks), "ncclCommCount");
+    POLUS_NCCL(g_rccl.CommUserRank(c->comm, rank), "ncclCommUserRank");
+    POLUS_NCCL(g_rccl.CommCuDevice(c->comm, device), "ncclCommCuDevice");
     return POLUS_OK;
 }
 

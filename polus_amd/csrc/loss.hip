@@ -264,7 +264,8 @@ extern "C" int polus_sigmoid_xent(int dtype, const float* logits, long ldl, cons
 
 // cm[r[i]][c[i]] += 1 for i < n (int32, exact): per-workgroup histogram in LDS, one atomic per non-zero cell
 __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restrict__ r, const int32_t* __restrict__ c,
-                                                        int64_t n, int C, int32_t* __restrict__ cm) {
+                                                        int64_t n, int C, int32_t* __restrict__ cm,
+                                                        int32_t* __restrict__ rejected) {
     extern __shared__ int hist[];
     const int cells = C * C;
     for (int k = threadIdx.x; k < cells; k += blockDim.x) hist[k] = 0;
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int a = r[i], b = c[i];
         if ((unsigned)a < (unsigned)C && (unsigned)b < (unsigned)C) atomicAdd(&hist[a * C + b], 1);
+        else if (rejected) atomicAdd(rejected, 1);      // out of [0, C): counted, never silently dropped
     }
     __syncthreads();
     for (int k = threadIdx.x; k < cells; k += blockDim.x)
@@ -279,13 +281,13 @@ __global__ __launch_bounds__(256) void confusion_kernel(const int32_t* __restric
 }
 
 extern "C" int polus_confusion_matrix(const int32_t* row_idx, const int32_t* col_idx, int64_t n, int C,
-                                      int32_t* cm, void* stream) {
+                                      int32_t* cm, int32_t* rejected, void* stream) {
     POLUS_REQUIRE(row_idx && col_idx && cm && n >= 0 && C > 0 && C <= 128, "polus_confusion_matrix: bad arguments (0 < C <= 128)");
     if (n == 0) return POLUS_OK;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(confusion_kernel, dim3(blocks), dim3(256), (size_t)C * C * sizeof(int), static_cast<hipStream_t>(stream),
-                       row_idx, col_idx, n, C, cm);
+                       row_idx, col_idx, n, C, cm, rejected);
     POLUS_CHECK_LAUNCH("polus_confusion_matrix");
     return POLUS_OK;
 }

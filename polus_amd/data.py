@@ -220,12 +220,22 @@ class _Prefetcher:
                 import torch
                 torch.cuda.set_device(self._device)
             for x in upstream:
-                if self._stop.is_set():
+                if not self._put(self._stage(x)):
                     return
-                self._q.put(self._stage(x))
-            self._q.put((self._END, None))
+            self._put((self._END, None))
         except BaseException as e:      # surface producer errors in the consumer
-            self._q.put((e, None))
+            self._put((e, None))
+
+    def _put(self, item):
+        """Blocking put that gives up once the consumer is gone (an abandoned iteration -- early_stop, take() --
+        must not leave this thread parked on a full queue holding pinned and device batches)."""
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def __iter__(self):
         return self
@@ -239,8 +249,28 @@ class _Prefetcher:
             raise x
         if ev is not None:
             import torch
-            torch.cuda.current_stream().wait_event(ev)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            # The batch was allocated under the prefetch stream: tell the caching allocator that the consumer's
+            # stream uses it too, or the block could be handed to the next prefetch copy (and overwritten) while
+            # kernels already queued on the compute stream -- embed_bwd reads the ids late in backward -- have
+            # not read it yet.
+
+            def mark(a):
+                if isinstance(a, torch.Tensor) and a.is_cuda:
+                    a.record_stream(cur)
+                return a
+            _tree_map(mark, x)
         return x
+
+    def close(self):
+        """Stops the producer thread and drops what it has staged."""
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
 
     def __del__(self):
         self._stop.set()

@@ -42,6 +42,29 @@ def _map_leaves(f, x):
     return f(x)
 
 
+def _reachable_tensors(roots, max_depth=8):
+    """Every torch.Tensor reachable from `roots` through attributes, dicts, lists and tuples."""
+    seen, out = set(), []
+    stack = [(r, 0) for r in roots]
+    while stack:
+        obj, depth = stack.pop()
+        if id(obj) in seen or obj is None:
+            continue
+        seen.add(id(obj))
+        if torch.is_tensor(obj):
+            out.append(obj)
+            continue
+        if depth >= max_depth or isinstance(obj, (str, bytes, int, float, bool, type)) or callable(obj) and not hasattr(obj, "__dict__"):
+            continue
+        if isinstance(obj, dict):
+            stack.extend((v, depth + 1) for v in obj.values())
+        elif isinstance(obj, (list, tuple, set)):
+            stack.extend((v, depth + 1) for v in obj)
+        elif hasattr(obj, "__dict__") and not isinstance(obj, type(torch)):
+            stack.extend((v, depth + 1) for v in vars(obj).values())
+    return out
+
+
 class GraphedStep:
     RING = 32          # pinned staging slots for the dynamic block (a slot is reused only after its copy ran)
 
@@ -119,6 +142,12 @@ class GraphedStep:
             model.overlap_dw = overlap
             opt.iterations, model.dropout_step, tr.step_counter_micro = it, ds, mc
         self.graph, self.captured_loss = g, loss.t
+        # The graph holds RAW POINTERS to every buffer the step touched: the shape-keyed activation / scratch caches of
+        # the model and its layers, the loss buffers, the optimizer slots, the workspace.  A later eager step of another
+        # batch shape (a short last batch) or an inference call between epochs replaces those cache entries and may grow
+        # the workspace; without these references the old blocks would return to the caching allocator and the next replay
+        # would read and write memory that other tensors own by then.
+        self._keepalive = _reachable_tensors([tr.model, tr.loss, opt, ws, self.static_in, list(ops._WS.values())])
         torch.cuda.synchronize()
 
     def __call__(self, *inputs):

@@ -55,16 +55,23 @@ class IConfusionMatrixTF(IMetric):
             from . import ops
             if self._dev_cm is None:
                 self._dev_cm = torch.zeros((self.num_classes, self.num_classes), dtype=torch.int32, device=y_true.device)
+                self._dev_rejected = torch.zeros(1, dtype=torch.int32, device=y_true.device)
             a = y_true.reshape(-1).to(torch.int32).contiguous()
             b = y_pred.reshape(-1).to(torch.int32).contiguous()
-            ops.confusion_matrix(a, b, self._dev_cm)
+            ops.confusion_matrix(a, b, self._dev_cm, self._dev_rejected)
             return
+        # host arrays, and device tensors with more than 128 classes (the kernel keeps its C x C histogram in LDS)
         self._host_cm += self._build_confusion_matrix(y_true, y_pred)
 
     def _build_confusion_matrix(self, y_true, y_pred):
         """tf.math.confusion_matrix: rows = first argument (polus/metrics.py:51-59)."""
         cm = np.zeros((self.num_classes, self.num_classes), np.int32)
-        np.add.at(cm, (_np(y_true).reshape(-1).astype(np.int64), _np(y_pred).reshape(-1).astype(np.int64)), 1)
+        r, c = _np(y_true).reshape(-1).astype(np.int64), _np(y_pred).reshape(-1).astype(np.int64)
+        bad = int(((r < 0) | (r >= self.num_classes) | (c < 0) | (c >= self.num_classes)).sum())
+        if bad:
+            raise ValueError(f"{self.name}: {bad} label / prediction value(s) outside [0, {self.num_classes}) "
+                             "(tf.math.confusion_matrix rejects them too)")
+        np.add.at(cm, (r, c), 1)
         return cm
 
     @property
@@ -72,11 +79,16 @@ class IConfusionMatrixTF(IMetric):
         """The counts so far (host int32 [C, C]); reading it synchronises with the device side."""
         if self._dev_cm is None:
             return self._host_cm
+        bad = int(self._dev_rejected.item())
+        if bad:
+            # same verdict as the host path (and as tf.math.confusion_matrix), raised where the counts are read
+            raise ValueError(f"{self.name}: {bad} label / prediction value(s) outside [0, {self.num_classes}) "
+                             "(tf.math.confusion_matrix rejects them too)")
         return self._host_cm + self._dev_cm.cpu().numpy()
 
     def reset(self):
         self._host_cm = np.zeros((self.num_classes, self.num_classes), np.int32)
-        self._dev_cm = None
+        self._dev_cm = self._dev_rejected = None
 
 
 def _divide_no_nan(a, b):

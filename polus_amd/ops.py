@@ -283,12 +283,14 @@ def argmax(x, out, rows=None, C=None):
     check(lib.polus_argmax(ptr(x), x.stride(0), ptr(out), rows, C, _st()), "polus_argmax")
 
 
-def confusion_matrix(row_idx, col_idx, cm):
-    """cm[row_idx[i], col_idx[i]] += 1 (int32 [C, C] on the device)."""
+def confusion_matrix(row_idx, col_idx, cm, rejected=None):
+    """cm[row_idx[i], col_idx[i]] += 1 (int32 [C, C] on the device); pairs with an index outside [0, C) are counted in
+    `rejected` (int32 [1] on the device) instead."""
     _req_cuda(row_idx, col_idx, cm)
     assert row_idx.dtype == torch.int32 and col_idx.dtype == torch.int32 and cm.dtype == torch.int32
     assert row_idx.numel() == col_idx.numel() and row_idx.is_contiguous() and col_idx.is_contiguous() and cm.is_contiguous()
-    check(_lib.load().polus_confusion_matrix(ptr(row_idx), ptr(col_idx), row_idx.numel(), cm.shape[0], ptr(cm), _st()),
+    check(_lib.load().polus_confusion_matrix(ptr(row_idx), ptr(col_idx), row_idx.numel(), cm.shape[0], ptr(cm),
+                                             ptr(rejected) if rejected is not None else None, _st()),
           "polus_confusion_matrix")
 
 

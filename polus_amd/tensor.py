@@ -142,9 +142,13 @@ class ParamArena:
     def finalize(self):
         if self.params is not None:
             return self
-        from . import comm, ops
-        # whole 256-byte lines per rank: a gradient reduce-scatter cuts the arena into `world` equal slices
-        q = ALIGN * max(1, comm.size())
+        from . import ops
+        # whole 256-byte lines per rank for every world size up to 8 (840 = lcm(1..8)): a gradient reduce-scatter
+        # cuts the arena into `world` equal slices.  The unit does not depend on the world size the process happens
+        # to run in (nor on whether comm was initialised before the model was built), so the arena of a model has ONE
+        # size: a training state saved on N GPUs resumes on any other N.  `extent` = the end of the last variable.
+        self.extent = self.size
+        q = ALIGN * 840
         self.size = (self.size + q - 1) // q * q
         host = np.zeros(self.size, np.float32)
         for v in self.vars:

@@ -154,11 +154,15 @@ class BaseTrainer:
         m = getattr(self, "_dp_mode_cached", None)
         if m is None:
             arenas = self._arenas()
+            want = os.environ.get("POLUS_DP_MODE", "allreduce") == "rs"
             ok = (len(arenas) == 1 and isinstance(self.optimizer, Adam) and not self.optimizer.global_clipnorm and
                   self.post_process_grads is None and hasattr(arenas[0], "size") and
                   arenas[0].grads.numel() % (64 * hvd.size()) == 0 and
-                  all(v.arena is arenas[0] for v in self.trainable_weights) and
-                  os.environ.get("POLUS_DP_MODE", "allreduce") == "rs")
+                  all(v.arena is arenas[0] for v in self.trainable_weights) and want)
+            if want and not ok:
+                logger.warning("POLUS_DP_MODE=rs was requested but this trainer cannot use it (it needs ONE arena swept by the "
+                               "fused Adam, no post_process_grads / global_clipnorm, and an arena of a multiple of "
+                               f"64 x {hvd.size()} elements): exchanging gradients by all-reduce instead")
             m = self._dp_mode_cached = "rs" if ok else "allreduce"
         return m
 
@@ -266,6 +270,7 @@ class BaseTrainer:
             self.model.grad_ready_hook = updater.on_ready
         self.backward_from_loss(accumulate=not first)
         self.step_counter_micro = micro + 1
+        self._exposed_mark(0)
         if updater is not None:
             self.model.grad_ready_hook = None
             updater.finish()
@@ -291,6 +296,7 @@ class BaseTrainer:
                 if hasattr(self.model, "grad_ready_hook"):
                     self.model.grad_ready_hook = None
                 dp_updater.finish()
+                self._exposed_mark(1)
                 return loss_value
             else:
                 # One arena, a fused optimizer and nothing that needs all gradients at once: keep the last
@@ -332,7 +338,23 @@ class BaseTrainer:
                 self.optimizer.apply_gradients([(v.grad, v) for v in lower], _advance=False)
         else:
             self.optimizer.apply_gradients(zip(grads, self.trainable_weights))
+        self._exposed_mark(1)
         return loss_value
+
+    def _exposed_mark(self, which):
+        """`trainer.measure_exposed = True` (bench.py, data-parallel runs): HIP events on the compute stream right behind
+        the last kernel of backward and behind the last thing the step queues -- the rest of the gradient exchange and
+        the optimizer update that nothing overlapped.  `trainer.exposed_events` = (begin, end) of the last step."""
+        if not (self.use_horovod and getattr(self, "measure_exposed", False)):
+            return
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if which == 0:
+            self._exposed_begin = ev
+        elif getattr(self, "_exposed_begin", None) is not None:
+            self.exposed_events = (self._exposed_begin, ev)
+            self._exposed_begin = None
 
     def lr_finder(self, tf_dataset, use_lr_found=False):
         pass
@@ -364,67 +386,72 @@ class BaseTrainer:
         hvd.broadcast_variables(self.trainable_weights, root_rank=0)
         hvd.broadcast_variables(self.optimizer.variables(), root_rank=0)
 
+    # ---- training loop
+    _MISSING = {"tf_dataset": "You need to pass a training dataset to the trainer.train method",
+                "epochs": "You need to pass the epochs variable to the trainer.train method"}
+
+    def _resolve_train_args(self, given):
+        """Arguments of train(): an explicit one wins, then `train_config` (changing_train_config), then -- for the
+        dataset and the epoch count only -- the ValueError of polus/training.py:251,257 (text is API)."""
+        resolved = {}
+        for name, value in given.items():
+            unset = value is None or (name == "callbacks" and len(value) == 0)
+            if unset and name in self.train_config:
+                value = self.train_config[name]
+            elif unset and name in self._MISSING:
+                raise ValueError(self._MISSING[name])
+            resolved[name] = value
+        return resolved
+
+    def _one_epoch(self, epoch, dataset, transform):
+        """Hook order of polus/training.py:305-330: on_train_batch_begin fires BEFORE the fetch (so once more when the
+        iterator is exhausted), the rank-0 broadcast precedes the first step of every epoch, step_counter is global."""
+        batches = iter(dataset)
+        in_epoch = 0
+        while True:
+            self.callbacks.on_train_batch_begin(epoch, in_epoch)
+            batch = next(batches, None)
+            if batch is None:
+                return
+            if transform is not None:
+                batch = transform(batch)
+            if in_epoch == 0 and self.use_horovod:
+                self.broadcast_init_vars()
+            loss = self.train_step(*batch)
+            self.callbacks.on_train_batch_end(epoch, in_epoch, loss)
+            self.step_counter += 1
+            in_epoch += 1
+            if self.early_stop:                  # polled after a step, never before the first one
+                return
+
     def train(self, tf_dataset=None, epochs=None, callbacks=[], train_map_f=None, steps=None, **kwargs):
-        """polus/training.py:213-338 — same hook order, including on_train_batch_begin firing
-        before the fetch (once extra at exhaustion) and the re-broadcast at step 0 of every
-        epoch."""
-        if tf_dataset is None:
-            if "tf_dataset" in self.train_config:
-                tf_dataset = self.train_config["tf_dataset"]
-            else:
-                raise ValueError("You need to pass a training dataset to the trainer.train method")
-        if epochs is None:
-            if "epochs" in self.train_config:
-                epochs = self.train_config["epochs"]
-            else:
-                raise ValueError("You need to pass the epochs variable to the trainer.train method")
-        if len(callbacks) == 0 and "callbacks" in self.train_config:
-            callbacks = self.train_config["callbacks"]
-        if train_map_f is None and "train_map_f" in self.train_config:
-            train_map_f = self.train_config["train_map_f"]
-        if steps is None and "steps" in self.train_config:
-            steps = self.train_config["steps"]
+        """polus/training.py:213-338: same signature, same hook order (see _one_epoch), same early-stop polling
+        (after a step and after an epoch's on_epoch_end)."""
+        a = self._resolve_train_args(dict(tf_dataset=tf_dataset, epochs=epochs, callbacks=callbacks,
+                                          train_map_f=train_map_f, steps=steps))
+        dataset, n_epochs, hooks, transform = a["tf_dataset"], a["epochs"], a["callbacks"], a["train_map_f"]
+        transform = kwargs.pop("custom_data_transform_f", transform)          # legacy spelling (polus/training.py:275-276)
 
-        if steps is None:
+        steps_per_epoch = a["steps"]
+        if steps_per_epoch is None:
             try:
-                N_STEPS = len(tf_dataset)
+                steps_per_epoch = len(dataset)
             except TypeError:
-                N_STEPS = -2  # tf.data UNKNOWN_CARDINALITY
-        else:
-            N_STEPS = steps
-
-        if "custom_data_transform_f" in kwargs:
-            train_map_f = kwargs.pop("custom_data_transform_f")
+                steps_per_epoch = -2                                          # tf.data UNKNOWN_CARDINALITY
 
         if os.getenv("POLUS_PROFILER", "False").lower() in ("true", "1", "t", "y", "yes"):
+            lo_hi = [int(x) for x in os.getenv("POLUS_PROFILER_RANGE", "10:20").split(":")]
             logger.info("POLUS_PROFILER env was set to True, so the Profiler callback was added to training")
-            profiler_step_range = list(map(int, os.getenv("POLUS_PROFILER_RANGE", "10:20").split(":")))
-            callbacks = list(callbacks) + [Profiler(steps_interval=profiler_step_range)]
+            hooks = list(hooks) + [Profiler(steps_interval=lo_hi)]            # a copy: the caller's list is left alone
 
-        if not isinstance(callbacks, CallbackCoordinator):
-            callbacks = CallbackCoordinator(callbacks, trainer=self, epochs=epochs, steps=N_STEPS)
-        self.callbacks = callbacks
+        if not isinstance(hooks, CallbackCoordinator):
+            hooks = CallbackCoordinator(hooks, trainer=self, epochs=n_epochs, steps=steps_per_epoch)
+        self.callbacks = hooks
+
         self.callbacks.on_train_begin()
-
-        for epoch in range(epochs):
+        for epoch in range(n_epochs):
             self.callbacks.on_epoch_begin(epoch)
-            _iter = iter(tf_dataset)
-            step = 0
-            while True:
-                self.callbacks.on_train_batch_begin(epoch, step)
-                data = next(_iter, None)
-                if data is None:
-                    break
-                if train_map_f is not None:
-                    data = train_map_f(data)
-                if step == 0 and self.use_horovod:
-                    self.broadcast_init_vars()
-                loss = self.train_step(*data)
-                self.callbacks.on_train_batch_end(epoch, step, loss)
-                self.step_counter += 1
-                step += 1
-                if self.early_stop:
-                    break
+            self._one_epoch(epoch, dataset, transform)
             self.callbacks.on_epoch_end(epoch)
             if self.early_stop:
                 break

@@ -258,6 +258,60 @@ def test_prefetch_stages_batches_in_hbm_and_confusion_matrix_on_gpu():
     assert abs(f1 - oo.macro_f1(oo.confusion_matrix(pred_all, ys, C))) < 1e-12
 
 
+def test_confusion_matrix_rejects_out_of_range_on_both_paths():
+    """A padding label (-100) or a wrong num_classes: tf.math.confusion_matrix raises; so do the host path
+    (at once) and the device path (when the counts are read) -- the same data never gives two different metrics."""
+    from polus_amd.metrics import Accuracy
+    y = np.array([0, 1, 2, -100, 1, 3], np.int32)
+    p = np.array([0, 1, 1, 2, 1, 0], np.int32)
+    host_metric = Accuracy(num_classes=3)
+    with pytest.raises(ValueError, match="outside"):
+        host_metric.samples_from_batch((p, y))
+    dev_metric = Accuracy(num_classes=3)
+    dev_metric.samples_from_batch((torch.from_numpy(p).cuda(), torch.from_numpy(y).cuda()))
+    with pytest.raises(ValueError, match="2 label"):
+        dev_metric.evaluate()
+    ok = Accuracy(num_classes=4)
+    ok.samples_from_batch((torch.from_numpy(p[[0, 1, 2, 4, 5]]).cuda(), torch.from_numpy(y[[0, 1, 2, 4, 5]]).cuda()))
+    assert abs(ok.evaluate() - 3 / 5) < 1e-12
+
+
+def test_prefetched_training_equals_unprefetched_without_host_syncs():
+    """Batches staged by Dataset.prefetch are allocated under the prefetch stream; the consumer marks them as used by the
+    compute stream (record_stream), so the allocator cannot hand a batch's block to the next copy while queued kernels
+    (the embedding backward reads the ids late in the step) have not read it.  Several steps with no host sync in
+    between must equal the same steps fed from host arrays."""
+    from polus_amd.data import Dataset
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import BertConfig, BertModel
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    g, ocfg, params, hw, hb = load_case("bert_small_b3_s48")
+    batches = []
+    for s in range(12):
+        ids, mask, tt, labels = synth_batch(ocfg, 3, 48, 4, 300 + s)
+        batches.append(({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels))
+
+    def run(prefetch):
+        cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                         ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size)
+        m = BertModel(cfg, compute_dtype="bf16", num_labels=hw.shape[0])
+        m.load_numpy_params(params, hw, hb)
+        m.deterministic = True
+        t = ClassifierTrainer(m, AdamWeightDecay(learning_rate=1e-3, weight_decay_rate=0.01),
+                              SparseCategoricalCrossentropy(grad_dtype=m.compute_dtype))
+        src = Dataset(lambda: iter(batches), len(batches))
+        it = src.prefetch(2) if prefetch else src
+        losses = [t.train_step(x, y) for x, y in it]          # no float(): nothing waits for the GPU between steps
+        out = [float(l) for l in losses]
+        torch.cuda.synchronize()
+        return out, m.arena.params.clone()
+    a, pa = run(False)
+    b, pb = run(True)
+    assert a == b and torch.equal(pa, pb)
+
+
 def test_global_clipnorm_is_one_norm_over_the_applied_variables():
     """tf.clip_by_global_norm semantics (polus/training.py:187-191 post_process_grads / Keras global_clipnorm):
     one norm over every variable handed to apply_gradients -- across two arenas -- and nothing else: a frozen
@@ -341,6 +395,52 @@ def test_graphed_step_equals_eager_step_bitwise(mode):
     assert eager == graphed, (eager, graphed)
     assert torch.equal(p_eager, p_graph)
     assert eager[-1] < eager[0]
+
+
+def test_graphed_step_survives_other_shapes_and_inference_between_replays():
+    """The captured graph holds raw pointers to the shape-keyed buffers of the model, the loss and the workspace.  A
+    short batch (runs eagerly), a LONGER batch (grows every cache and the workspace) and an inference call between
+    replays replace those cache entries; GraphedStep keeps the captured buffers alive, so the replays that follow
+    must still equal the eager run bit for bit -- with unrelated allocations in between that would land in any block
+    the graph had wrongly released."""
+    from polus_amd.losses import SparseCategoricalCrossentropy
+    from polus_amd.models import BertConfig, BertModel
+    from polus_amd.optimizers import AdamWeightDecay
+    from polus_amd.training import ClassifierTrainer
+    from tests.golden.make_golden import synth_batch
+    g, ocfg, params, hw, hb = load_case("bert_small_b3_s48")
+    plan = [(3, 48)] * 4 + [(2, 32), (3, 48), (5, 64), (3, 48), "infer", (3, 48), (3, 48)]
+
+    def run(graphed):
+        cfg = BertConfig(ocfg.vocab_size, ocfg.hidden_size, ocfg.num_hidden_layers, ocfg.num_attention_heads,
+                         ocfg.intermediate_size, ocfg.max_position_embeddings, ocfg.type_vocab_size,
+                         hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+        m = BertModel(cfg, compute_dtype="bf16", num_labels=hw.shape[0])
+        m.load_numpy_params(params, hw, hb)
+        m.deterministic = True
+        t = ClassifierTrainer(m, AdamWeightDecay(learning_rate=1e-3, weight_decay_rate=0.01),
+                              SparseCategoricalCrossentropy(grad_dtype=m.compute_dtype))
+        if graphed:
+            t.enable_step_graph(warmup=2)
+        losses, junk = [], []
+        for s, item in enumerate(plan):
+            if item == "infer":
+                ids, mask, tt, _ = synth_batch(ocfg, 4, 40, 4, 900)
+                m({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, training=False)
+                continue
+            B, S = item
+            ids, mask, tt, labels = synth_batch(ocfg, B, S, 4, 700 + s)
+            losses.append(t.train_step({"input_ids": ids, "attention_mask": mask, "token_type_ids": tt}, labels))
+            # allocations that would reuse freed blocks of the captured step, filled with a poison value
+            junk = [torch.full((1 << 18,), float("nan"), device=m.arena.device) for _ in range(8)]
+        out = [float(l) for l in losses]
+        torch.cuda.synchronize()
+        del junk
+        return out, m.arena.params.clone()
+    eager, p_eager = run(False)
+    graphed, p_graph = run(True)
+    assert eager == graphed, (eager, graphed)
+    assert torch.equal(p_eager, p_graph)
 
 
 @pytest.mark.parametrize("mode,accum", [("bf16", 1), ("f32", 1), ("bf16", 2)])

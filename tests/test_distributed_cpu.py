@@ -36,3 +36,17 @@ def test_world_size_two_gloo():
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
         assert f"rank {rank} OK" in out
+
+
+def test_bench_bare_launch_spawns_ranks_and_relays_failure():
+    """`python bench.py --gpus 2` without a launcher: the parent must spawn two ranks with a working rendezvous and, when
+    the ranks fail (no GPU here: "bench.py needs an MI355X"), exit non-zero instead of hanging or printing a line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert r.stderr.count("needs an MI355X") >= 1 and "launch with torch.distributed.run" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -119,3 +119,24 @@ def test_native_rccl_plane_world_1():
     assert torch.equal(x, ref) and torch.equal(h.float(), torch.arange(4096, dtype=torch.float32, device="cuda").to(torch.bfloat16).float())
     assert lib.polus_comm_broadcast(plane.comm, x.data_ptr(), 16, 3, None) != 0 and b"bad root" in lib.polus_last_error()
     plane.close()
+
+
+def test_bench_bare_multi_gpu_launch_line(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it: the parent spawns both ranks (before it touches torch or
+    the GPU), rank 0 prints the one JSON line, and the N > 1 line describes its own exchange: how many ranks the data
+    plane really spanned, which plane, the exposed tail behind backward and the step time with no exchange at all.
+    Two ranks share the box's one GPU, so the wire is gloo (RCCL refuses duplicate devices)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(POLUS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--layers", "2", "--batch", "8", "--seq", "64", "--no-f32-leg", "--no-loss100", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["data_plane"] == "gloo"
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["exposed_comm_ms"] > 0 and out["ms_per_step_nocomm"] > 0 and out["ms_per_step"] > 0
+    assert out["value"] > 0 and out["roofline"]["launches"] > 0 and "unpinned" in out["multi_gpu_parity"]
