@@ -31,10 +31,8 @@ static inline bool polus_aligned16(const void* p) { return (((uintptr_t)p) & 15)
 // The POLUS_* environment switches (A/B runs, tests) are read ONCE at library load -- a getenv per
 // launch sat on the launch path of every GEMM -- and again only through polus_reload_env().
 struct PolusCfg {
-    int gemm_p;            // POLUS_GEMM_P: 0 off, 1 persistent 256x192 where a tile writes little per FLOP, 2 wherever legal
     int gemm_pp;           // POLUS_GEMM_PP: -1 off, 0 per-shape choice (default), 256 / 192 force that tile where legal
     int gemm_v1;           // POLUS_GEMM_V1: 128x128 register-staged kernel for everything
-    int gemm_256;          // POLUS_GEMM_256: one-workgroup-per-CU 256x256 kernel (A/B)
     int ring_runtime_epi;  // POLUS_RING_RUNTIME_EPI: ring kernel with run-time epilogue flags (A/B)
     int dw_ungrouped;      // POLUS_DW_UNGROUPED: one dW launch per matrix
     int ablate;            // POLUS_GEMM_ABLATE: diagnostics (bit0 no in-loop DMA, bit1 no MFMA)

@@ -294,21 +294,19 @@ static int polus_num_cus() {
     }
     return n;
 }
-// The persistent 256x192 kernel (gemm_p.hip): higher FLOP per filled byte than the ring kernel, but
-// with one wave per SIMD nothing overlaps its epilogue.  It was 9 % ahead on the N <= K shapes until
-// the ring kernel got compile-time epilogue modes too; now the two tie in the training step
-// (4010 vs 4024 samples/s), so it is opt-in: POLUS_GEMM_P=1 uses it where a tile has little to
-// write per FLOP (N <= K, no second store or load stream), POLUS_GEMM_P=2 wherever it is legal
-// (tests).  Needs K % 64 == 0, N % 192 == 0 and (nearly) full rounds of #CU tiles.
-static bool use_persistent(int M, int N, int K, int mode) {
-    const int sel = polus_cfg().gemm_p;
-    if (sel == 0 || mode < 0 || K % 64 != 0 || M < 256 || N < 192) return false;
-    if (sel == 2) return true;
-    if (!(mode == 0 || mode == 2) || N > K || (N % 192) != 0) return false;
-    const int ncu = polus_num_cus();
-    const long tiles = (long)((M + 255) / 256) * (N / 192);
-    const long rounds = (tiles + ncu - 1) / ncu;
-    return tiles * 100 >= rounds * ncu * 90;
+// Epilogue class of a bf16-C launch for the kernels with compile-time epilogues (gemm_pp.hip, the 128 x 128 ring tile):
+// 0 = alpha / bias, 1 = activation forward (+ pre-activation to aux), 2 = residual (+ dropout), 3 = activation backward
+// (aux read); -1 = a combination they are not built for (the caller stays on the run-time epilogue of the ring kernel).
+int polus_gemm_epi_mode(const GemmArgs& a, int c_is_f32, int drop) {
+    if (c_is_f32 || (a.flags & POLUS_GEMM_ACCUM_C) || a.partial) return -1;
+    const bool fwd = a.flags & POLUS_GEMM_ACT_FWD, bwd = a.flags & POLUS_GEMM_ACT_BWD;
+    if (fwd && (bwd || a.resid || drop)) return -1;
+    if (bwd && (a.resid || drop || !a.aux)) return -1;
+    if (drop && !a.resid) return -1;
+    if (fwd) return 1;
+    if (bwd) return 3;
+    if (a.resid) return 2;
+    return 0;
 }
 
 // The ping-pong kernel (gemm_pp.hip, one 8-wave workgroup per CU, 256 x 256 or 256 x 192 tile): more
@@ -497,10 +495,9 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
         POLUS_REQUIRE(both_kc && c_dtype == dtype, "polus_gemm_dropout: needs K-contiguous operands and c_dtype == dtype");
         if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !polus_cfg().gemm_v1) {
             a.k_per_split = ((K + 31) / 32) * 32;
-            if (const int tn = pp_tile(M, N, K, polus_gemm_p_mode(a, 0, 1), a.epi_vec16))
-                return polus_launch_gemm_pp(a, polus_gemm_p_mode(a, 0, 1), 1, tn, st);
-            if (use_persistent(M, N, K, polus_gemm_p_mode(a, 0, 1))) return polus_launch_gemm_p(a, polus_gemm_p_mode(a, 0, 1), 1, 192, polus_num_cus(), st);
-            if (use_ring128(M, N, K, polus_gemm_p_mode(a, 0, 1))) return polus_launch_gemm_ring128(a, polus_gemm_p_mode(a, 0, 1), 1, st);
+            if (const int tn = pp_tile(M, N, K, polus_gemm_epi_mode(a, 0, 1), a.epi_vec16))
+                return polus_launch_gemm_pp(a, polus_gemm_epi_mode(a, 0, 1), 1, tn, st);
+            if (use_ring128(M, N, K, polus_gemm_epi_mode(a, 0, 1))) return polus_launch_gemm_ring128(a, polus_gemm_epi_mode(a, 0, 1), 1, st);
             return polus_launch_gemm_ring_dropout(a, st);
         }
         const bool v = a.a_vec && a.b_vec;
@@ -510,17 +507,13 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     const int a_ks = a_layout == POLUS_K_STRIDED, b_ks = b_layout == POLUS_K_STRIDED;
     if (dtype == POLUS_BF16 && a.a_vec && a.b_vec && M >= 256 && N >= 128 && !polus_cfg().gemm_v1) {
         if (split_k <= 1) {
-            // POLUS_GEMM_256=1 selects the one-workgroup-per-CU 256x256 kernel (kept for A/B runs)
-            if (both_kc && polus_cfg().gemm_256 && N >= 192) return polus_launch_gemm256(a, c_dtype == POLUS_F32, st);
             a.k_per_split = ((K + 31) / 32) * 32;
             if (both_kc) {
-                if (const int tn = pp_tile(M, N, K, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), a.epi_vec16))
-                    return polus_launch_gemm_pp(a, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), 0, tn, st);
+                if (const int tn = pp_tile(M, N, K, polus_gemm_epi_mode(a, c_dtype == POLUS_F32, 0), a.epi_vec16))
+                    return polus_launch_gemm_pp(a, polus_gemm_epi_mode(a, c_dtype == POLUS_F32, 0), 0, tn, st);
             }
-            if (both_kc && use_persistent(M, N, K, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0)))
-                return polus_launch_gemm_p(a, polus_gemm_p_mode(a, c_dtype == POLUS_F32, 0), 0, 192, polus_num_cus(), st);
-            if (both_kc && c_dtype == POLUS_BF16 && use_ring128(M, N, K, polus_gemm_p_mode(a, 0, 0)))
-                return polus_launch_gemm_ring128(a, polus_gemm_p_mode(a, 0, 0), 0, st);
+            if (both_kc && c_dtype == POLUS_BF16 && use_ring128(M, N, K, polus_gemm_epi_mode(a, 0, 0)))
+                return polus_launch_gemm_ring128(a, polus_gemm_epi_mode(a, 0, 0), 0, st);
             return polus_launch_gemm_ring(a, c_dtype == POLUS_F32, a_ks, b_ks, 1, st);
         }
         GemmArgs s = a;              // slabs: plain f32 stores, epilogue applied by the reduce kernel

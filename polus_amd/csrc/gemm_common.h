@@ -1,5 +1,5 @@
-// Shared by the two MFMA GEMM kernels (gemm.hip: 128x128 general; gemm256.hip: 256x256 bf16
-// direct-to-LDS): launch arguments and the fused epilogue.
+// Shared by the MFMA GEMM kernels (gemm.hip: 128x128 general; gemm_ring.hip / gemm_pp.hip / gemm_ppks.hip: bf16
+// direct-to-LDS): launch arguments and the fused epilogues.
 #pragma once
 #include "common.h"
 
@@ -209,7 +209,7 @@ __device__ __forceinline__ void epilogue_wave_128x64_lds(const GemmArgs& p, f32x
 
 
 // ---------------------------------------------------------------------------------------------
-// Shared by gemm_p.hip and (K-contiguous operands, bf16 C) gemm_ring.hip.
+// (K-contiguous operands, bf16 C) gemm_ring.hip.
 template <int WN> struct EpiCfg {
     static constexpr int RS = WN * 4 + 16;            // staging row stride (f32 row of the wave + pad)
     static constexpr int BYTES = 9 * RS;              // half an m-tile (8 rows) + one dump row
@@ -230,7 +230,7 @@ template <bool AGPR> __device__ __forceinline__ f32x4 acc_take(f32x4& acc) {
 // MODE (compile time, so that variants without loads carry no vmcnt waits between their stores --
 // vmcnt retires in order, a wait for a residual load would also wait for every older C store):
 //   0 = alpha/bias only, 1 = ACT_FWD (+ pre-activation to aux), 2 = residual (+ dropout), 3 = ACT_BWD (aux read)
-// AGPR: the accumulators are pinned to AGPRs by inline-asm MFMAs (gemm_p.hip) or live in VGPRs (gemm_ring.hip).
+// AGPR: the accumulators are pinned to AGPRs by inline-asm MFMAs, or live in VGPRs (gemm_ring.hip).
 template <typename TC, int WN, bool DROP, int MODE, bool AGPR>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8][WN / 16], int mb, int nb,
                                               int lane, unsigned char* lds) {
@@ -497,12 +497,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 }  // namespace pgemm
 
-// gemm256.hip: bf16, both operands K-contiguous, whole 16-byte chunks.  c_is_f32 selects TC.
-int polus_launch_gemm256(const pgemm::GemmArgs& a, int c_is_f32, hipStream_t st);
 // gemm_ring.hip: same contract, 256x128 tile, two workgroups per CU.
 // a_ks / b_ks: operand stored [K][rows]; splits > 1: blockIdx.y selects [y*k_per_split, ..) and C + y*c_split_stride.
 int polus_launch_gemm_ring(const pgemm::GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st);
-// gemm_ring.hip: 128 x 128 tile, three workgroups per CU, both operands K-contiguous, bf16 C, mode from polus_gemm_p_mode:
+// gemm_ring.hip: 128 x 128 tile, three workgroups per CU, both operands K-contiguous, bf16 C, mode from polus_gemm_epi_mode:
 // for launches whose 256-row tiles would leave most of the chip idle (a few thousand tokens).
 int polus_launch_gemm_ring128(const pgemm::GemmArgs& a, int mode, int drop, hipStream_t st);
 // several dW problems (both operands K-strided, f32 C / slabs, same K and k_per_split) in one launch
@@ -510,11 +508,10 @@ int polus_launch_gemm_ring128(const pgemm::GemmArgs& a, int mode, int drop, hipS
 int polus_launch_gemm_ring_grouped_dw(const pgemm::GemmArgs* probs, int n, const int* splits, hipStream_t st);
 // dropout epilogue (POLUS_GEMM_DROPOUT): bf16 C, both operands K-contiguous only.
 int polus_launch_gemm_ring_dropout(const pgemm::GemmArgs& a, hipStream_t st);
-// gemm_p.hip: persistent 256 x tn tile (tn = 192), one workgroup per CU, both operands K-contiguous, K % 64 == 0.
-int polus_gemm_p_mode(const pgemm::GemmArgs& a, int c_is_f32, int drop);   // -1: not built for this epilogue
-int polus_launch_gemm_p(const pgemm::GemmArgs& a, int mode, int drop, int tn, int ncu, hipStream_t st);
+// gemm.hip: compile-time epilogue class of a launch (0 bias, 1 act fwd, 2 residual (+ dropout), 3 act bwd; -1: none fits)
+int polus_gemm_epi_mode(const pgemm::GemmArgs& a, int c_is_f32, int drop);
 // gemm_pp.hip: 256 x tn tile (tn = 256 or 192), 8 waves in two half-phase-staggered groups, one workgroup per
-// CU, both operands K-contiguous, K % 64 == 0, bf16 C, mode from polus_gemm_p_mode.
+// CU, both operands K-contiguous, K % 64 == 0, bf16 C, mode from polus_gemm_epi_mode.
 int polus_launch_gemm_pp(const pgemm::GemmArgs& a, int mode, int drop, int tn, hipStream_t st);
 // gemm_ppks.hip: the grouped dW launch on 256 x 256 tiles (both operands K-strided, f32 C / slabs, K % 64 == 0),
 // and the one-launch reduction of a group's slabs and bias-gradient partials.

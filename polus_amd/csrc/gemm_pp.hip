@@ -279,7 +279,7 @@ int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
 
 }  // namespace
 
-// tn = 256 or 192; mode from polus_gemm_p_mode (>= 0); K % 64 == 0; bf16 C; 16-byte aligned rows.
+// tn = 256 or 192; mode from polus_gemm_epi_mode (>= 0); K % 64 == 0; bf16 C; 16-byte aligned rows.
 int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStream_t st) {
     if (mode < 0 || a.K % TK != 0 || a.K < TK) return POLUS_ERR_INVALID;
     if (tn == 256) return launch_pp_mode<4>(a, mode, drop, st);

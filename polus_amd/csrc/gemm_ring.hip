@@ -2,7 +2,7 @@
 // C[M,N] = A[M,K] . B[N,K]^T, both operands K-contiguous (forward Dense; dX through the
 // transposed weight shadow).
 //
-// Why two workgroups per CU: with one 8-wave workgroup per CU (gemm256.hip) the per-tile
+// Why two workgroups per CU: with one un-staggered 8-wave workgroup per CU (round 1's 256 x 256 kernel, removed) the per-tile
 // prologue (first loads), epilogue (bias/GELU/residual + C stores, which also have to drain
 // before the next counted wait because vmcnt retires in order) and the LDS-read part of every
 // phase leave the matrix pipe idle, and K = 768 gives only 12 K-steps per tile to amortise them.
@@ -436,13 +436,13 @@ int polus_launch_gemm_ring128(const GemmArgs& a, int mode, int drop, hipStream_t
 }
 
 int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
-    if (polus_gemm_p_mode(a, 0, 1) == 2 && !polus_cfg().ring_runtime_epi) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
+    if (polus_gemm_epi_mode(a, 0, 1) == 2 && !polus_cfg().ring_runtime_epi) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
     return launch_ring<bf16_t, false, false, true>(a, 1, st);
 }
 
 int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st) {
     if (!c_is_f32 && !a_ks && !b_ks && splits == 1 && !polus_cfg().ring_runtime_epi) {
-        switch (polus_gemm_p_mode(a, 0, 0)) {      // same epilogue classes as the persistent kernel
+        switch (polus_gemm_epi_mode(a, 0, 0)) {      // same epilogue classes as the persistent kernel
             case 0: return launch_ring<bf16_t, false, false, false, 0>(a, 1, st);
             case 1: return launch_ring<bf16_t, false, false, false, 1>(a, 1, st);
             case 2: return launch_ring<bf16_t, false, false, false, 2>(a, 1, st);

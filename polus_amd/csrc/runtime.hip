@@ -20,10 +20,8 @@ static int env_int(const char* name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 static void read_cfg() {
-    g_cfg.gemm_p = env_int("POLUS_GEMM_P", 0);
     g_cfg.gemm_pp = env_int("POLUS_GEMM_PP", 0);
     g_cfg.gemm_v1 = getenv("POLUS_GEMM_V1") != nullptr;
-    g_cfg.gemm_256 = getenv("POLUS_GEMM_256") != nullptr;
     g_cfg.ring_runtime_epi = getenv("POLUS_RING_RUNTIME_EPI") != nullptr;
     g_cfg.dw_ungrouped = getenv("POLUS_DW_UNGROUPED") != nullptr;
     g_cfg.ablate = env_int("POLUS_GEMM_ABLATE", 0);

@@ -486,10 +486,10 @@ def test_sqnorm_clip_cast_scale(ops):
     assert_close(host(g_t), g * 0.25, 1e-7, "scale")
 
 
-# ------------------------------------------------------------------------------- 256x256 direct-to-LDS GEMM
+# ------------------------------------------------------------------------------- direct-to-LDS GEMMs (ring / ping-pong, chosen per shape)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 768), (300, 200, 72), (1000, 520, 264),
                                    (257, 193, 8), (2048, 3072, 768), (1024, 768, 3072)])
-def test_gemm256_matches_reference_and_v1(ops, M, N, K, monkeypatch):
+def test_gemm_lds_dma_matches_reference_and_v1(ops, M, N, K, monkeypatch):
     r = rng(M + N + K)
     A, B = r.standard_normal((M, K)), r.standard_normal((N, K))
     a_t, b_t = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
@@ -511,7 +511,7 @@ def test_gemm256_matches_reference_and_v1(ops, M, N, K, monkeypatch):
     assert torch.equal(o32, o2)
 
 
-def test_gemm256_epilogues_and_identity(ops):
+def test_gemm_lds_dma_epilogues_and_identity(ops):
     M, N, K = 384, 256, 192
     r = rng(77)
     A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.2
@@ -625,48 +625,6 @@ def test_dense_bwd_params(ops, dtype, T, n_out, n_in, sk):
     ops.dense_bwd_params(dy_t, x_t, dw, db, accumulate=True, split_k=sk)
     assert_close(host(dw), 2 * host(w0), 1e-6, "dW accumulate")
     assert_close(host(db), 2 * host(b0), 1e-6, "db accumulate")
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 192, 64), (512, 384, 128), (2048, 768, 768), (300, 400, 192), (1000, 192, 1536),
-                                   (4096, 768, 3072)])
-def test_gemm_persistent_256x192(ops, M, N, K, monkeypatch):
-    """gemm_p.hip (persistent 256x192, one workgroup per CU): every epilogue mode it is built for,
-    interior / ragged / several-tiles-per-workgroup shapes, against the oracle arithmetic and
-    bit-for-bit against the ring kernel (same MFMA k-order)."""
-    r = rng(M + 7 * N + K)
-    A, B = r.standard_normal((M, K)), r.standard_normal((N, K)) * 0.1
-    bias, R, U = r.standard_normal(N), r.standard_normal((M, N)), r.standard_normal((M, N))
-    dt = torch.bfloat16
-    a_t, b_t, bias_t, r_t, u_t = dev(A, dt), dev(B, dt), dev(bias, torch.float32), dev(R, dt), dev(U, dt)
-    base = rounded(A, dt) @ rounded(B, dt).T
-    tol = TOL[dt]
-
-    def both(**kw):
-        outs = []
-        for sel in ("2", "0"):
-            ops.set_env("POLUS_GEMM_P", sel)
-            out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
-            kw2 = dict(kw)
-            if kw2.get("aux") == "new":
-                kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
-            ops.gemm(a_t, b_t, out, **kw2)
-            outs.append((out, kw2.get("aux")))
-        ops.set_env("POLUS_GEMM_P")
-        assert torch.equal(outs[0][0], outs[1][0]), "persistent kernel differs from the ring kernel"
-        return outs[0]
-
-    out, _ = both(bias=bias_t)
-    assert_close(host(out), base + bias, tol, "bias")
-    out, aux = both(bias=bias_t, aux="new", act="gelu", flags=ops.GEMM_ACT_FWD)
-    assert_close(host(aux), base + bias, tol, "aux")
-    assert_close(host(out), ob.gelu(base + bias), tol, "gelu")
-    out, _ = both(bias=bias_t, resid=r_t)
-    assert_close(host(out), base + bias + rounded(R, dt), tol, "bias+resid")
-    out, _ = both(aux=u_t, act="gelu", flags=ops.GEMM_ACT_BWD)
-    assert_close(host(out), base * ob.gelu_grad(rounded(U, dt)), tol, "gelu bwd")
-    out, _ = both(bias=bias_t, resid=r_t, drop_p=0.25, seed=123)
-    keep = host(ops.dropout_mask(123, 0.25, M * N)).astype(np.float64).reshape(M, N)
-    assert_close(host(out), (base + bias) * keep / 0.75 + rounded(R, dt), tol, "dropout+resid")
 
 
 @pytest.mark.parametrize("tn", [256, 192])

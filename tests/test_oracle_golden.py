@@ -236,6 +236,27 @@ def test_schedule_table_against_reference_closed_form():
             assert abs(oo.warmup_linear_lr(t, N, lr, pct) - ref) <= 1e-18 + 1e-15 * ref, (N, t)
 
 
+def test_schedule_pinned_to_hf_polynomial_decay_with_warmup():
+    """An INDEPENDENT implementation of the same schedule: transformers.optimization.get_polynomial_decay_schedule_with_warmup
+    (power 1, lr_end 1e-7) is the PyTorch twin of HF-TF's WarmUp over PolynomialDecay that polus/schedulers.py:10-23
+    builds.  The oracle's closed form and the product's WarmUpLinearDecay must follow it at every step of a run and past
+    its end."""
+    import torch
+    from transformers.optimization import get_polynomial_decay_schedule_with_warmup
+    from polus_amd.optimizers import WarmUpLinearDecay
+    for N, pct, lr in ((100, 0.1, 1e-3), (1000, 0.1, 5e-5), (37, 0.25, 2e-4)):
+        W = int(N * pct)
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+        sched = get_polynomial_decay_schedule_with_warmup(opt, num_warmup_steps=W, num_training_steps=N, lr_end=1e-7, power=1.0)
+        mine = WarmUpLinearDecay(N, lr, pct)
+        for t in range(0, N + 20):
+            ref = sched.get_last_lr()[0]
+            assert abs(oo.warmup_linear_lr(t, N, lr, pct) - ref) <= 1e-12 * lr, (N, t, ref)
+            assert abs(mine(t) - ref) <= 1e-12 * lr, (N, t, ref)
+            opt.step()
+            sched.step()
+
+
 def test_torch_cpu_port_matches_numpy_oracle():
     """oracle/bert_torch.py (the cpu_baseline leg of bench.py) computes the same step as the NumPy
     oracle: loss, logits, every gradient (autograd vs the explicit backward) and three AdamW steps."""
