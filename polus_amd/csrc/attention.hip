@@ -227,6 +227,237 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(AttnArgs p) {
     if (qvalid && g == 0) p.lse[((long)b * p.A + h) * S + q] = m * LN2 + __logf(l);
 }
 
+// ---------------------------------------------------------------- forward, bf16: LDS-DMA ring, 128 keys per softmax pass
+// One workgroup = NW waves = 16 NW queries of one (batch, head).  K and V arrive by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, nothing returns to a VGPR, so the only waits in the kernel are the counted ones written below)
+// into a ring of four 64-key blocks [K 64 x 128 B | V 64 x 128 B]; rows are packed (128 B) and the bank swizzle sits on
+// the SOURCE address: LDS chunk pc of row r holds d-chunk pc ^ (r & 7) -- conflict-free for the ds_read_b128 row reads
+// of K and for the ds_read_b64_tr_b16 column reads of V (the XOR is a lane constant: key block bases are multiples of 8).
+// The DMA of the first four blocks (all of a 256-token sequence) is issued before anything is computed; block j's
+// scores are computed behind a counted `vmcnt` that leaves the later blocks in flight, and a slot is refilled (longer
+// sequences) as soon as both blocks of a pass have been consumed.  The online softmax advances 128 keys per pass: one
+// row-max exchange per 128 keys instead of per 64, the row sums stay per lane until the end (the rescale factor is the
+// same in the four lanes of a query).  Q and the key mask also come by LDS-DMA (Q into the fourth ring slot, which is
+// refilled once the fragments are in registers); the output goes back through LDS so that HBM sees whole 128-byte rows.
+// Same arithmetic per score as attn_fwd_kernel (scale, additive -10000 mask, base-2 exponentials, dropout after the
+// row sum); the sums are taken in a different order, so results agree to rounding, not bit for bit.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+__device__ __forceinline__ void dma16(const void* g, unsigned char* lds) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lds_void_t*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* g, unsigned char* lds) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lds_void_t*)lds, 4, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// all but the `left * PPW` youngest LDS-DMA pieces of this wave have landed
+template <int PPW> __device__ __forceinline__ void wait_blocks_left(int left) {
+    if (left >= 3) wait_vm<3 * PPW>(); else if (left == 2) wait_vm<2 * PPW>(); else if (left == 1) wait_vm<PPW>(); else wait_vm<0>();
+}
+__device__ __forceinline__ float xor16(float v) {      // lane ^ 16 (inside a half wave): the swizzle unit, no LDS memory
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ float col_max2(float v) {
+    v = fmaxf(v, xor16(v));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float col_sum2(float v) {
+    v += xor16(v);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr int FWD_RING = 4, FWD_STAGE = 2 * BLK * 128;   // ring slots; 16 KiB per 64-key block (K | V)
+constexpr int FWD_MAX_S = 1024;                          // key-bias block in LDS: 4 B per key
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attn_fwd_dma_kernel(AttnArgs p) {
+    typedef bf16_t T;
+    constexpr int QB = 16 * NW, NT = 64 * NW, PPW = 16 / NW;      // pieces (8 rows x 128 B) per wave and K/V block
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;                                   // [4][K 8 KiB | V 8 KiB]
+    float* kbc = reinterpret_cast<float*>(smem + FWD_RING * FWD_STAGE);   // [S rounded up to 64 NW] key bias, log2 units
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
+    const int S = p.S, H = p.H;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const int q = q0 + wid * 16 + i;
+    const int r8 = lane >> 3, src_chunk = ((lane & 7) ^ r8) * 8;  // this lane's row inside a piece, its d-chunk (elements)
+
+    auto issue_block = [&](int j) {                               // 64 keys from j * 64 into ring slot j & 3
+        unsigned char* st = ring + (j & 3) * FWD_STAGE;
+#pragma unroll
+        for (int e = 0; e < PPW; ++e) {
+            const int piece = wid + e * NW;                       // 0-7: K rows 8 piece.., 8-15: V rows 8 (piece - 8)..
+            const int row = min(j * BLK + (piece & 7) * 8 + r8, S - 1);
+            dma16(qkv + (long)row * ld + (piece < 8 ? H : 2 * H) + h * D + src_chunk, st + piece * 1024);
+        }
+    };
+    const int nblk = (S + BLK - 1) / BLK;
+    // ---- prologue: the key mask of the whole sequence (ints for now), Q (into ring slot 3), blocks 0-2
+    if (p.mask)
+        for (int k0 = wid * 64; k0 < S; k0 += 64 * NW)
+            dma4(p.mask + (long)b * S + min(k0 + lane, S - 1), reinterpret_cast<unsigned char*>(kbc) + k0 * 4);
+    {
+        unsigned char* qs = ring + 3 * FWD_STAGE;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int piece = wid + e * NW;
+            dma16(qkv + (long)min(q0 + piece * 8 + r8, S - 1) * ld + h * D + src_chunk, qs + piece * 1024);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (j < nblk) issue_block(j);
+    wait_blocks_left<PPW>(min(nblk, 3));                          // mask and Q have landed
+    __builtin_amdgcn_s_barrier();
+    Frag<T> qf[2];
+    {
+        const int row = wid * 16 + i;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+            qf[sub].v = *reinterpret_cast<const bf16x8*>(ring + 3 * FWD_STAGE + row * 128 + (((sub * 4 + g) ^ (row & 7)) * 16));
+    }
+    for (int t = tid; t < nblk * BLK; t += NT) {                  // mask -> additive bias, in place (same thread reads and writes a word)
+        float bias = 0.0f;
+        if (p.mask) bias = (1.0f - (float)reinterpret_cast<const int*>(kbc)[t]) * MASK_NEG;
+        kbc[t] = t < S ? bias * LOG2E : -INFINITY;
+    }
+    wait_lgkm();
+    __builtin_amdgcn_s_barrier();                                 // Q fragments in registers everywhere: slot 3 is free
+    if (nblk > 3) issue_block(3);
+    int issued = min(nblk, 4);
+
+    const float scale2 = p.scale * LOG2E;
+    float m = -1e30f, l = 0.f;                                    // l: this lane's share of the row sum (4 lanes per query)
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kx = i & 7;                                         // row & 7 of every K row this lane reads (rows 16 kt + i)
+    const int k_off0 = i * 128 + ((g ^ kx) * 16), k_off1 = i * 128 + (((4 + g) ^ kx) * 16);
+    // V^T fragment: rows 32 ks + 4 g + (i >> 2) (+16), d-chunk 2 dt + ((i & 3) >> 1), half (i & 1)
+    const int vrow = 4 * g + (i >> 2), vx = vrow & 7;
+    const int v_base = vrow * 128 + (i & 1) * 8, v_c = (i & 3) >> 1;
+
+    for (int j0 = 0; j0 < nblk; j0 += 2) {
+        const bool two = j0 + 1 < nblk;
+        // ---- scores of the pass: S^T tiles [64 keys x 16 queries] per block, each behind its counted wait
+        f32x4 s[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (jj == 0 || two) {
+                wait_blocks_left<PPW>(issued - 1 - (j0 + jj));     // the later blocks stay in flight
+                __builtin_amdgcn_s_barrier();
+                const unsigned char* Kt = ring + ((j0 + jj) & 3) * FWD_STAGE;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    s[jj][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    Frag<T> a0, a1;
+                    a0.v = *reinterpret_cast<const bf16x8*>(Kt + kt * 2048 + k_off0);
+                    a1.v = *reinterpret_cast<const bf16x8*>(Kt + kt * 2048 + k_off1);
+                    mma16(s[jj][kt], a0, qf[0]);                  // D[key 4g+r][query i]
+                    mma16(s[jj][kt], a1, qf[1]);
+                }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) s[jj][kt] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+        }
+        // ---- softmax step over the (up to) 32 scores of this lane; 4 lanes (g) share a query
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            if (jj == 0 || two) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const f32x4 kb = *reinterpret_cast<const f32x4*>(kbc + (j0 + jj) * BLK + kt * 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[jj][kt][r] = fmaf(s[jj][kt][r], scale2, kb[r]);      // log2 units
+                    mx = fmaxf(mx, fmaxf(fmaxf(s[jj][kt][0], s[jj][kt][1]), fmaxf(s[jj][kt][2], s[jj][kt][3])));
+                }
+            }
+        mx = col_max2(mx);
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        float rs = 0.f;
+        Frag<T> pf[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[jj][kt][r] = __builtin_amdgcn_exp2f(s[jj][kt][r] - m_new); rs += s[jj][kt][r]; }
+            if (p.drop_thresh) {   // the row sum uses the undropped probabilities (softmax first, then dropout)
+                const unsigned rowb = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + (j0 + jj) * BLK + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    float t4[4] = {s[jj][kt][0], s[jj][kt][1], s[jj][kt][2], s[jj][kt][3]};
+                    polus_dropout_run<4>(t4, p.drop_seed, rowb + kt * 16, p.drop_thresh, p.drop_inv, (S & 3) == 0);
+                    s[jj][kt] = (f32x4){t4[0], t4[1], t4[2], t4[3]};
+                }
+            }
+            frag_from_acc(pf[jj][0], s[jj][0], s[jj][1]);
+            frag_from_acc(pf[jj][1], s[jj][2], s[jj][3]);
+        }
+        l = l * alpha + rs;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        // ---- O^T += V^T P^T (a missing second block has P = 0: its slot holds finite leftovers or never-read bytes... skip it)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (jj == 0 || two) {
+                const unsigned char* Vt = ring + ((j0 + jj) & 3) * FWD_STAGE + BLK * 128 + v_base;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const unsigned char* vp = Vt + ks * 4096 + (((2 * dt + v_c) ^ vx) * 16);
+                        const s16x4 lo = lds_tr16(vp), hi = lds_tr16(vp + 16 * 128);
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        Frag<T> va;
+                        va.v = __builtin_bit_cast(bf16x8, w);
+                        mma16(o[dt], va, pf[jj][ks]);             // D[d 4g+r][query i]
+                    }
+            }
+        }
+        // ---- longer sequences: both slots of this pass are free once every wave is past its reads; refill them
+        if (j0 + 4 < nblk) {
+            wait_lgkm();
+            __builtin_amdgcn_s_barrier();
+            issue_block(j0 + 4);
+            ++issued;
+            if (j0 + 5 < nblk) { issue_block(j0 + 5); ++issued; }
+        }
+    }
+    // ---- output: normalise, stage this wave's 16 x 64 tile in LDS (ring slot 0, wave-private 2 KiB, same chunk swizzle),
+    // store whole 128-byte rows
+    l = col_sum2(l);
+    const float inv_l = 1.0f / l;
+    wait_lgkm();
+    __builtin_amdgcn_s_barrier();                                 // every wave is done reading K / V (and no DMA is in flight)
+    unsigned char* ot = ring + wid * 2048;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        float v[4] = {o[dt][0] * inv_l, o[dt][1] * inv_l, o[dt][2] * inv_l, o[dt][3] * inv_l};
+        store4<T>(reinterpret_cast<T*>(ot + i * 128 + (((2 * dt + (g >> 1)) ^ (i & 7)) * 16) + (g & 1) * 8), v);
+    }
+    wait_lgkm();
+    T* ctx = static_cast<T*>(p.ctx) + (long)b * S * H;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = 8 * t + r8, qq = q0 + wid * 16 + row;
+        const uint4 v = *reinterpret_cast<const uint4*>(ot + row * 128 + (lane & 7) * 16);
+        if (qq < S) *reinterpret_cast<uint4*>(ctx + (long)qq * H + h * D + (((lane & 7) ^ (row & 7)) * 8)) = v;
+    }
+    if (q < S && g == 0) p.lse[((long)b * p.A + h) * S + q] = m * LN2 + __logf(l);
+}
+
 // ---------------------------------------------------------------- dQ
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -614,6 +845,18 @@ int launch_wide_nw(const AttnArgs& a, hipStream_t st) {
     return POLUS_OK;
 }
 template <int NW>
+int launch_fwd_dma(const AttnArgs& a, hipStream_t st) {
+    auto kern = attn_fwd_dma_kernel<NW>;
+    const size_t lds = FWD_RING * FWD_STAGE + (size_t)((a.S + 64 * NW - 1) / (64 * NW)) * 64 * NW * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.S + 16 * NW - 1) / (16 * NW), a.A, a.B), dim3(64 * NW), lds, st, a);
+    return POLUS_OK;
+}
+template <int NW>
 int launch_fused(const AttnArgs& a, int n_heads, int B, size_t lds, hipStream_t st) {
     auto kern = attn_bwd_fused_kernel<NW>;
     static bool attr_done = false;
@@ -647,7 +890,11 @@ extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* ma
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
     a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p); a.dyn = polus_dyn();
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc2 = launch_wide<0>(dtype, a, st);
+    int rc2;
+    if (dtype == POLUS_BF16 && polus_cfg().attn_fwd_dma && S <= FWD_MAX_S)
+        rc2 = S >= 96 ? launch_fwd_dma<8>(a, st) : launch_fwd_dma<4>(a, st);
+    else
+        rc2 = launch_wide<0>(dtype, a, st);
     if (rc2 != POLUS_OK) return rc2;
     POLUS_CHECK_LAUNCH("polus_attention_fwd");
     return POLUS_OK;

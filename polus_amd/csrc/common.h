@@ -43,6 +43,9 @@ struct PolusCfg {
     int gemm_ring128;      // POLUS_GEMM_RING128: -1 never, 0 (default) where the heuristic picks it, 1 wherever it applies (bf16 C, K-contiguous operands)
     int gemm_auto_split;   // POLUS_GEMM_AUTO_SPLIT: 1 (default) polus_gemm_auto_split recommends K slices for under-filled bf16 Dense GEMMs; 0 = always 1
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
+    int gemm_order;        // POLUS_GEMM_ORDER: column tiles an XCD's concurrent ping-pong tiles span (0 = row-major run; default 4)
+    int reserve_cus;       // POLUS_GEMM_RESERVE_CUS: CUs the tile-shape choice leaves to concurrent RCCL channel kernels (default 0)
+    int attn_fwd_dma;      // POLUS_ATTN_FWD_DMA: 1 (default) LDS-DMA / whole-row-softmax attention forward (bf16); 0 = the register-staged kernel
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward for S in {64, 128, 256} (bf16)
 };
 const PolusCfg& polus_cfg();

@@ -318,7 +318,10 @@ static int pp_tile(int M, int N, int K, int mode, bool vec16) {
     const int sel = polus_cfg().gemm_pp;
     if (sel < 0 || mode < 0 || K % 64 != 0 || M < 256 || N < 192 || !vec16) return 0;
     if (sel == 256 || sel == 192) return sel;
-    const int ncu = polus_num_cus();
+    // CUs a launch can count on: all of them, minus what a concurrent gradient exchange holds (POLUS_GEMM_RESERVE_CUS: a
+    // ping-pong workgroup fills a CU's registers and LDS, so a CU running an RCCL channel kernel takes no tile, and a
+    // 256-tile launch that finds 240 free CUs runs two rounds)
+    const int ncu = max(32, polus_num_cus() - polus_cfg().reserve_cus);
     const long tm = (M + 255) / 256;
     double best = 0.0; int best_tn = 0;
     for (int tn : {256, 192}) {
@@ -456,6 +459,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     if (aux) ev16 = ev16 && (((uintptr_t)aux) % 16 == 0) && ((ldaux * es) % 16 == 0);
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
     a.ablate = polus_cfg().ablate;
+    a.order = polus_cfg().gemm_order;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
@@ -604,6 +608,7 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     a.a_vec = a.b_vec = 1;
     a.colsum_a = cs_ws;
     a.ablate = polus_cfg().ablate;
+    a.order = polus_cfg().gemm_order;
     int rc;
     if (splits_eff > 1) {
         a.C = ws; a.ldc = n_in; a.c_split_stride = (long)n_out * n_in;
@@ -755,6 +760,7 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         a.a_vec = a.b_vec = 1;
         a.colsum_a = q.db ? reinterpret_cast<float*>(ws + co[k]) : nullptr;
         a.ablate = ablate;
+        a.order = 0;
         if (eff[k] > 1) {
             a.C = ws + so[k]; a.ldc = q.n_in; a.c_split_stride = (long)q.n_out * q.n_in;
             a.epi_vec = a.epi_vec16 = (q.n_in % 4 == 0);

@@ -23,6 +23,7 @@ struct GemmArgs {
     float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
+    int order;   // gemm_pp.hip: column tiles the concurrent tiles of one XCD span (0 = its run in row-major order)
     const PolusDyn* dyn;  // per-step scalars in device memory (graph replay) or null: kernels with a dropout epilogue
                           // replace drop_seed by polus_eff_seed(drop_seed, dyn) on entry
 };
@@ -493,6 +494,26 @@ __device__ __forceinline__ void epilogue_wave_db(const GemmArgs& p, f32x4 (&acc)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
     return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+}
+
+// Tile of workgroup `bid` in a grid of `nwg` = tiles_m x tiles_n tiles, XCD-aware.  Every XCD owns a contiguous run of
+// row-major tiles (xcd_remap).  order = 0: the run is walked in row-major order -- an XCD's ~32 concurrent tiles then
+// span 2-3 row panels x ALL column tiles, so every XCD streams the whole weight matrix through its 4 MiB L2 in every
+// round (FFN1: 4.7 MB of W per round, 150 MB fetched per launch against 30 MB of operands).  order = c > 0 (when the
+// run is whole rows and c divides tiles_n): the run is walked in blocks of R rows x c columns, row-major inside a block,
+// so the concurrent tiles of an XCD share c weight column panels and R activation row panels.
+__device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_n, int order, int& row, int& col) {
+    const int per = nwg >> 3;
+    if (order > 0 && (nwg & 7) == 0 && per % tiles_n == 0 && tiles_n % order == 0 && tiles_n > order) {
+        const int xcd = bid & 7, j = bid >> 3, R = per / tiles_n, blk = R * order;
+        const int b = j / blk, jj = j - b * blk;
+        row = xcd * R + jj / order;
+        col = b * order + jj % order;
+        return;
+    }
+    const int wg = xcd_remap(bid, nwg);
+    row = wg / tiles_n;
+    col = wg - row * tiles_n;
 }
 
 }  // namespace pgemm

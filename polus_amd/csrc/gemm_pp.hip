@@ -85,8 +85,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
         }
     }
     const int tiles_n = (p.N + TN - 1) / TN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
+    int trow, tcol;
+    tile_of(blockIdx.x, gridDim.x, tiles_n, p.order, trow, tcol);
+    const int m0 = trow * TM, n0 = tcol * TN;
     const int nk = p.K / TK;
 
     // ---- LDS-DMA sources.  Rows past the edge are clamped (their accumulators are never stored).

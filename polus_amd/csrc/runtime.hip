@@ -25,9 +25,12 @@ static void read_cfg() {
     g_cfg.ring_runtime_epi = getenv("POLUS_RING_RUNTIME_EPI") != nullptr;
     g_cfg.dw_ungrouped = getenv("POLUS_DW_UNGROUPED") != nullptr;
     g_cfg.ablate = env_int("POLUS_GEMM_ABLATE", 0);
+    g_cfg.gemm_order = env_int("POLUS_GEMM_ORDER", 4);
+    g_cfg.reserve_cus = env_int("POLUS_GEMM_RESERVE_CUS", 0);
     g_cfg.attn_waves = env_int("POLUS_ATTN_WAVES", 0);
     g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
     g_cfg.attn_fused = env_int("POLUS_ATTN_FUSED", 1);
+    g_cfg.attn_fwd_dma = env_int("POLUS_ATTN_FWD_DMA", 1);
     g_cfg.ln_halfwave = env_int("POLUS_LN_HALFWAVE", 1);
     g_cfg.gemm_auto_split = env_int("POLUS_GEMM_AUTO_SPLIT", 1);
     g_cfg.gemm_ring128 = env_int("POLUS_GEMM_RING128", 0);

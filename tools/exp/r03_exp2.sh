@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python3 -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "attention" > gpurun_out/r03_attn_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r03_attn_tests.log
+tail -15 gpurun_out/r03_attn_tests.log
+python3 tools/attn_bench.py > gpurun_out/r03_attn_bench.txt 2>&1 && python3 tools/attn_bench.py --seq 512 --batch 16 >> gpurun_out/r03_attn_bench.txt 2>&1 && python3 tools/attn_bench.py --seq 128 --batch 32 >> gpurun_out/r03_attn_bench.txt 2>&1
+cat gpurun_out/r03_attn_bench.txt

@@ -23,6 +23,20 @@ def timed(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+def timed_cold(fn, iters, scrub):
+    """Events around each launch alone; a 512 MiB pass in between evicts the operands from L2 and the Infinity Cache."""
+    pairs = []
+    for _ in range(iters):
+        scrub.add_(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in pairs) / iters * 1e-3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--T", type=int, default=16384)
@@ -30,7 +44,13 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--variants", default="-1,256,192")
+    ap.add_argument("--ab", default=None, help="NAME=v1,v2,..: A/B another library switch (POLUS_GEMM_PP stays on its per-shape choice)")
+    ap.add_argument("--cold", action="store_true", help="touch 512 MiB between launches (operands no longer L2 / Infinity-Cache warm)")
     args = ap.parse_args()
+    env_name = "POLUS_GEMM_PP"
+    if args.ab:
+        env_name, vals = args.ab.split("=")
+        args.variants = vals
     H, I = (1024, 4096) if args.large else (768, 3072)
     T = args.T
     dt, dev = torch.bfloat16, "cuda"
@@ -41,7 +61,9 @@ def main():
               ("ffn2 fwd", H, I, "drop+resid"), ("dx qkv", H, 3 * H, "resid"), ("dctx", H, H, "plain"),
               ("du (ffn2 dx)", I, H, "gelu-bwd"), ("da1 (ffn1 dx)", H, I, "resid")]
     sels = [int(v) for v in args.variants.split(",")]
-    print(f"{'gemm':14s} {'N':>5s} {'K':>5s} {'epilogue':11s} " + " ".join(f"{('ring' if s < 0 else 'pp' + str(s)):>16s}" for s in sels))
+    label = (lambda s: 'ring' if s < 0 else 'pp' + str(s)) if not args.ab else (lambda s: f"{env_name[6:]}={s}")
+    print(f"{'gemm':14s} {'N':>5s} {'K':>5s} {'epilogue':11s} " + " ".join(f"{label(s):>16s}" for s in sels))
+    scrub = torch.empty(512 << 20, dtype=torch.uint8, device=dev) if args.cold else None
     tot = {s: 0.0 for s in sels}
     totfl = 0.0
     for name, N, K, epi in shapes:
@@ -59,15 +81,15 @@ def main():
         best = {s: 1e9 for s in sels}
         med = {s: [] for s in sels}
         for s in sels:
-            ops.set_env("POLUS_GEMM_PP", s)
+            ops.set_env(env_name, s)
             timed(fn, 3)
         for _ in range(args.rounds):
             for s in sels:
-                ops.set_env("POLUS_GEMM_PP", s)
-                t = timed(fn, args.iters)
+                ops.set_env(env_name, s)
+                t = timed_cold(fn, args.iters, scrub) if args.cold else timed(fn, args.iters)
                 best[s] = min(best[s], t)
                 med[s].append(t)
-        ops.set_env("POLUS_GEMM_PP")
+        ops.set_env(env_name)
         cells = []
         for s in sels:
             m = sorted(med[s])[len(med[s]) // 2]
