@@ -248,6 +248,22 @@ def init():
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    if use_gpu and backend != "gloo":
+        # RCCL's channel kernels are persistent workgroups, one CU each, for as long as a collective runs.  The GEMMs of the
+        # step keep ONE 512-thread, 128 KiB workgroup per CU (all of a CU's registers and LDS), so a CU that runs a channel
+        # takes no tile: cap the channels (POLUS_RCCL_MAX_CHANNELS, default 16; an explicit NCCL_MAX_NCHANNELS wins) and let
+        # the GEMM tile-shape choice plan for that many CUs fewer (POLUS_GEMM_RESERVE_CUS; csrc/gemm.hip pp_tile), so that a
+        # 256-tile launch does not find 240 CUs and run two rounds.  The exchange has ~8 ms of backward to hide under and
+        # needs ~60 GB/s per direction and link for that: 16 channels are ample.
+        cap = os.environ.get("POLUS_RCCL_MAX_CHANNELS", "16")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", cap)
+        if "POLUS_GEMM_RESERVE_CUS" not in os.environ:
+            os.environ["POLUS_GEMM_RESERVE_CUS"] = os.environ["NCCL_MAX_NCHANNELS"]
+            try:
+                from . import _lib
+                _lib.check(_lib.load().polus_reload_env(), "polus_reload_env")
+            except Exception:       # noqa: BLE001 -- the library is loaded (and reads its switches) later in that case
+                pass
     if not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rk, world_size=world,
@@ -414,6 +430,19 @@ class GradBucketReducer:
             cuts = [c for c in cuts if 0 <= c < n]
             if not cuts or cuts[0] != 0:
                 cuts = [0] + cuts
+            # a tensor larger than a bucket (the word-embedding table: 89 MB of gradient against 64 MB buckets) is cut
+            # into equal parts of whole 256-byte lines: its first part's all-reduce is on the wire while the update of
+            # nothing but the LAST part stays exposed behind it, instead of one 89 MB collective followed by one
+            # 89 MB optimizer sweep at the very end of the step
+            fine = []
+            for lo_c, hi_c in zip(cuts, cuts[1:] + [n]):
+                fine.append(lo_c)
+                if hi_c - lo_c > elems:
+                    parts = -(-(hi_c - lo_c) // elems)
+                    step = -(-(hi_c - lo_c) // parts)
+                    step = (step + 511) // 512 * 512
+                    fine += [c for c in range(lo_c + step, hi_c, step)]
+            cuts = fine
             buckets, hi = [], n
             lo_idx = len(cuts) - 1
             while hi > 0:

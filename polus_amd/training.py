@@ -71,14 +71,30 @@ class _UpdateBehindAllReduce(_UpdateInBackward):
     compute stream) -- no further fence is needed.  What stays exposed after backward is the last bucket (the
     embeddings) and its update."""
 
+    def begin(self):
+        super().begin()
+        self.part_left = {}                  # id(v) -> elements of a tensor cut across buckets that are still to be updated
+
     def on_bucket(self, lo, hi, work):
         vs = [v for v in self.vars if id(v) in self.left and lo <= v.offset and v.offset + v.size <= hi]
+        # tensors larger than a bucket (the word-embedding table) are cut across several: update the part inside this one
+        parts = [v for v in self.vars if id(v) in self.left and v.offset < hi and v.offset + v.size > lo and
+                 not (lo <= v.offset and v.offset + v.size <= hi)]
+        opt = self.trainer.optimizer
         with _lib.stream_scope(self.stream):
             work.wait()                      # the update stream (not the compute stream) waits for this bucket
             if vs:
-                self.trainer.optimizer.apply_gradients([(v.grad, v) for v in vs], _advance=self.first, _refresh=False)
+                opt.apply_gradients([(v.grad, v) for v in vs], _advance=self.first, _refresh=False)
                 self.arena.refresh_transposed_of(vs)
                 self.first = False
+            for v in parts:
+                a, b = max(lo, v.offset), min(hi, v.offset + v.size)
+                opt.apply_gradients([(v.grad, v)], _advance=self.first, _refresh=False, _ranges=[(a, b)])
+                self.first = False
+                self.part_left[id(v)] = self.part_left.get(id(v), v.size) - (b - a)
+                if self.part_left[id(v)] <= 0:
+                    self.arena.refresh_transposed_of([v])
+                    del self.left[id(v)]
         for v in vs:
             del self.left[id(v)]
 

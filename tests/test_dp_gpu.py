@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "allreduce_accum2", "allreduce_epochs2", "allreduce_bf16", "rs", "rs_accum2", "rs_bf16", "rs_epochs2"])
+@pytest.mark.parametrize("mode", ["allreduce", "allreduce_split", "allreduce_accum2", "allreduce_epochs2", "allreduce_bf16", "rs", "rs_accum2", "rs_bf16", "rs_epochs2"])
 def test_two_ranks_equal_one_rank_with_the_whole_batch(tmp_path, mode):
     from polus_amd.losses import SparseCategoricalCrossentropy
     from polus_amd.optimizers import AdamWeightDecay
