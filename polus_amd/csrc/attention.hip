@@ -116,6 +116,7 @@ struct AttnArgs {
     unsigned drop_thresh, drop_seed;   // attention-probability dropout; mask index ((b*A+h)*S+q)*S+key
     float drop_inv;
     const PolusDyn* dyn;               // per-step scalars in device memory (graph replay) or null
+    int debug;                         // diagnostics (POLUS_ATTN_DEBUG): parts of the key-resident backward switched off
 };
 
 __device__ __forceinline__ float key_bias(const int32_t* mask, int b, int S, int key) {
@@ -815,6 +816,352 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
     store_acc_T<T>(dqkv, ld, q, h * D, dq, 1.0f, g, true);
 }
 
+// ---------------------------------------------------------------- backward in one pass, key-resident (bf16, S % 256 == 0)
+// One workgroup = 8 waves = 256 keys of one (batch, head); wave w owns keys 32 w .. 32 w + 31 and keeps their dK^T and
+// dV^T ([64 d x 32 keys] each) in registers while the workgroup sweeps the queries in slices of 32.  Per slice:
+//   A  S = Q K^T and dP = dO V^T with the QUERY on the MFMA row and the key on the lane (K and V rows live in registers
+//      as the column operands); the exponential, the dropout mask and dS once per score; the dropped probabilities P'
+//      and dS are then ALREADY the column operands of dV^T += dO^T P' and dK^T += Q^T dS (contraction over the slice's
+//      queries), so neither crosses LDS; only dS does, once, as bf16 [key][query];
+//   B  dQ^T of the slice ([64 d x 32 q] = 8 tiles, one per wave) over all 256 keys: K^T fragments (registers, loaded
+//      once) x dS^T (transposing LDS reads) -- final for this key block, no sum across waves.
+// One barrier per slice: dS is double-buffered, dQ tiles are staged in LDS and leave as whole 128-byte rows one slice
+// later.  Q and dO slices come by LDS-DMA two to three slices ahead behind counted waits (every transposing read is
+// inline asm: the compiler would otherwise drain the prefetch with vmcnt(0) before each of them).
+// Sequences longer than 256 keys take one workgroup per 256-key block: dK / dV are still final per workgroup; the dQ
+// tiles go to an f32 slab per key block and attn_bwd_dq_finish_kernel adds the slabs in block order.
+// The dropout mask is indexed ((b A + h) S + q) S + key with one hash per FOUR CONSECUTIVE KEYS; here a lane holds four
+// queries of one key, so each lane hashes the quad of ONE of its queries and the four lanes of a key quad exchange the
+// hashes by DPP -- the mask is bit-identical to the forward's.
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_off(const unsigned char* p) { return (unsigned)(unsigned long)(const lds_u8*)p; }
+// fragment = rows r..r+3 (elements 0-3) and r+16..r+19 (elements 4-7) of a transposing read; ROW16 = byte distance of 16 rows
+template <int ROW16>
+__device__ __forceinline__ void tr_pair_asm(Frag<bf16_t>& f, unsigned addr) {
+    v2i_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(ROW16));
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const v4i_t w = {lo[0], lo[1], hi[0], hi[1]};
+    f.v = __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ void ds_read128_asm(Frag<bf16_t>& f, unsigned addr) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    v4i_t w;
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(w) : "v"(addr));
+    f.v = __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ uint2 ds_read64_asm(unsigned addr) {
+    v2i_t w;
+    asm volatile("ds_read_b64 %0, %1" : "=&v"(w) : "v"(addr));
+    return make_uint2((unsigned)w[0], (unsigned)w[1]);
+}
+__device__ __forceinline__ void lds_fence() {            // results of the inline-asm reads above are in their registers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// value of lane (lane & ~3) + R of each quad of four lanes
+template <int R> __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, R | (R << 2) | (R << 4) | (R << 6), 0xF, 0xF, true);
+}
+
+constexpr int KR_KEYS = 256, KR_QS = 32, KR_RING = 4;
+constexpr int KR_KV = KR_KEYS * 128;                 // K image / V image
+constexpr int KR_SLICE = KR_QS * 128;                // a 32-query slice of Q or of dO
+constexpr int KR_DS = 2 * KR_KEYS * 32;              // one dS buffer: [q-tile][key][16 q] bf16
+constexpr int KR_OFF_RING = 2 * KR_KV, KR_OFF_DS = KR_OFF_RING + KR_RING * 2 * KR_SLICE, KR_OFF_DQ = KR_OFF_DS + 2 * KR_DS,
+              KR_OFF_STAT = KR_OFF_DQ + 2 * KR_SLICE;   // + [S] lse (log2 units) + [S] delta
+
+__global__ __launch_bounds__(512, 2) void attn_bwd_kres_kernel(AttnArgs p, float* __restrict__ dq_slabs) {
+    typedef bf16_t T;
+    constexpr int NT = 512;
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kimg = smem;
+    unsigned char* Vimg = smem + KR_KV;
+    unsigned char* ring = smem + KR_OFF_RING;          // [4][Q slice 4 KiB | dO slice 4 KiB]
+    unsigned char* dsb = smem + KR_OFF_DS;             // [2][2][256][32 B]
+    unsigned char* dqb = smem + KR_OFF_DQ;             // [2][32 q][128 B]
+    float* lsec = reinterpret_cast<float*>(smem + KR_OFF_STAT);
+    const int S = p.S, H = p.H;
+    float* deltac = lsec + S;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int key0 = kb * KR_KEYS;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const T* dctx = static_cast<const T*>(p.dctx) + (long)b * S * H;
+    T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
+    const int r8 = lane >> 3, src_chunk = ((lane & 7) ^ r8) * 8;
+    const int nsl = S / KR_QS;
+
+    // ---- LDS-DMA: K / V images of this key block (4 + 4 pieces per wave), then query slices 0-2 (one piece per wave and slice)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int piece = wid + 8 * e;                 // rows 8 piece ..
+        const long row = (long)(key0 + piece * 8 + r8) * ld + h * D + src_chunk;
+        dma16(qkv + row + H, Kimg + piece * 1024);
+        dma16(qkv + row + 2 * H, Vimg + piece * 1024);
+    }
+    auto issue_slice = [&](int t) {                    // wave w: piece w of [Q rows 0-31 | dO rows 0-31] of slice t
+        const int q = t * KR_QS + (wid & 3) * 8 + r8;
+        unsigned char* dst = ring + (t & 3) * 2 * KR_SLICE + wid * 1024;
+        if (wid < 4) dma16(qkv + (long)q * ld + h * D + src_chunk, dst);
+        else dma16(dctx + (long)q * H + h * D + src_chunk, dst);
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t) if (t < nsl) issue_slice(t);
+    // ---- per-query statistics: lse (log2 units) and delta = rowsum(dO * O); ordinary loads, consumed before the loop.
+    // Whole rows per wave instruction (8 lanes x 16 B = one 128-byte head row, 8 rows per instruction), partial sums
+    // folded over the 8 lanes of a row.
+    {
+        const T* ctx = static_cast<const T*>(p.ctx) + (long)b * S * H;
+        const long stat0 = ((long)b * p.A + h) * S;
+        for (int q8 = wid * 8; q8 < S; q8 += 256) {              // 64 rows per pass of the workgroup, 4 passes in flight
+            bf16x8 o[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                          // every load first: one memory latency, not four
+                const int q = q8 + 64 * u + r8;
+                if (!(p.debug & 8)) {
+                    o[u] = *reinterpret_cast<const bf16x8*>(ctx + (long)q * H + h * D + (lane & 7) * 8);
+                    d[u] = *reinterpret_cast<const bf16x8*>(dctx + (long)q * H + h * D + (lane & 7) * 8);
+                } else { o[u] = (bf16x8)(bf16_t)0.f; d[u] = o[u]; }
+            }
+            float l4[4];
+            if ((lane & 7) == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) l4[u] = p.lse[stat0 + q8 + 64 * u + r8];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float dl = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)o[u][j] * (float)d[u][j];
+                // the 8 lanes of a row: lane ^ 1, ^ 2, ^ 4 through the swizzle unit (no LDS memory)
+                dl += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, dl), 0x041F));
+                dl += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, dl), 0x081F));
+                dl += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, dl), 0x101F));
+                if ((lane & 7) == 0) { deltac[q8 + 64 * u + r8] = dl; lsec[q8 + 64 * u + r8] = l4[u] * LOG2E; }
+            }
+        }
+    }
+    float kb2[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) kb2[kt] = key_bias(p.mask, b, S, key0 + wid * 32 + kt * 16 + i) * LOG2E;
+    wait_vm<0>();
+    wait_lgkm();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- operands that stay in registers: K / V rows of my 32 keys (column operands of S and dP), K^T of my dQ tile
+    const int my_dt = wid & 3, my_qt = wid >> 2;
+    Frag<T> kf[2][2], vf[2][2], ktr[8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int row = wid * 32 + kt * 16 + i, off = row * 128 + (((sub * 4 + g) ^ (row & 7)) * 16);
+            ds_read128_asm(kf[kt][sub], lds_off(Kimg + off));
+            ds_read128_asm(vf[kt][sub], lds_off(Vimg + off));
+        }
+    // transposing reads of a [rows][128 B] image with chunk swizzle: rows r0 + 4 g + (i >> 2) (+16), columns 16 dt + 4 (i & 3) ..
+    const int trow = 4 * g + (i >> 2), tx = trow & 7, thalf = (i & 1) * 8, tc = (i & 3) >> 1;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        tr_pair_asm<16 * 128>(ktr[ks], lds_off(Kimg + (ks * 32 + trow) * 128 + (((2 * my_dt + tc) ^ tx) * 16) + thalf));
+    lds_fence();
+    // dS = P (dP - delta) / sqrt(d): 1/sqrt(d) = 0.125 is a power of two, so scaling the bf16 K^T operand of dQ (and the
+    // dK^T sums at the end) instead of every dS is exact -- same bits, one multiply per score less
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ktr[ks].v[j] = (bf16_t)((float)ktr[ks].v[j] * p.scale);
+
+    f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const float scale2 = p.scale * LOG2E;
+    // row reads of a slice: rows 16 qt + i, d-chunk 4 sub + g
+    const int rr_off0 = i * 128 + ((g ^ (i & 7)) * 16), rr_off1 = i * 128 + (((4 + g) ^ (i & 7)) * 16);
+    // dS staging: image qt, row = my key, granule g ^ ((row >> 2) & 3)
+    int ds_w[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) { const int row = wid * 32 + kt * 16 + i; ds_w[kt] = row * 32 + ((g ^ ((row >> 2) & 3)) * 8); }
+    // dS^T reads (phase B): image my_qt, rows 32 ks + 4 g + (i >> 2) (+16), granule (i & 3) ^ ((row >> 2) & 3): (row >> 2) & 3 = g
+    const int ds_r = my_qt * (KR_KEYS * 32) + trow * 32 + (((i & 3) ^ (g & 3)) * 8);
+    const unsigned hash_row = ((unsigned)b * p.A + h) * S;      // + q, then * S + key
+    const int my_r = i & 3;                                       // the query (of each group of four) whose quad this lane hashes
+
+    f32x4 dq_prev = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nsl; ++t) {
+        const unsigned char* sl = ring + (t & 3) * 2 * KR_SLICE;
+        const int q0 = t * KR_QS;
+        // ---- phase A
+        Frag<T> qr[2][2], dor[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            ds_read128_asm(qr[qt][0], lds_off(sl + qt * 2048 + rr_off0));
+            ds_read128_asm(qr[qt][1], lds_off(sl + qt * 2048 + rr_off1));
+            ds_read128_asm(dor[qt][0], lds_off(sl + KR_SLICE + qt * 2048 + rr_off0));
+            ds_read128_asm(dor[qt][1], lds_off(sl + KR_SLICE + qt * 2048 + rr_off1));
+        }
+        lds_fence();
+        f32x4 s[2][2], dp[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dp[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                mma16(s[qt][kt], qr[qt][0], kf[kt][0]);          // D[query 4g+r][key i]
+                mma16(s[qt][kt], qr[qt][1], kf[kt][1]);
+                mma16(dp[qt][kt], dor[qt][0], vf[kt][0]);
+                mma16(dp[qt][kt], dor[qt][1], vf[kt][1]);
+            }
+        // the transposed slice operands of dV^T / dK^T: issued now, consumed after the element-wise part
+        Frag<T> qT[4], doT[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int off = trow * 128 + (((2 * dt + tc) ^ tx) * 16) + thalf;
+            tr_pair_asm<16 * 128>(qT[dt], lds_off(sl + off));
+            tr_pair_asm<16 * 128>(doT[dt], lds_off(sl + KR_SLICE + off));
+        }
+        Frag<T> pf[2], dsf[2];
+        if (!(p.debug & 2))
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const f32x4 l2 = *reinterpret_cast<const f32x4*>(lsec + q0 + qt * 16 + 4 * g);
+            const f32x4 de = *reinterpret_cast<const f32x4*>(deltac + q0 + qt * 16 + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                unsigned h1 = 0, h2 = 0;
+                if (p.drop_thresh) {       // quad (query q0 + 16 qt + 4 g + my_r, keys 4 (key >> 2) ..): one hash per lane
+                    const unsigned key = key0 + wid * 32 + kt * 16 + i;
+                    const unsigned idx = (hash_row + (unsigned)(q0 + qt * 16 + 4 * g + my_r)) * (unsigned)S + (key & ~3u);
+                    h1 = polus_hash32(p.drop_seed, idx >> 2);
+                    h2 = polus_hash32_second(h1);
+                }
+                float pd[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], scale2, kb2[kt]) - l2[r]);
+                    float pk = pr, dpe = dp[qt][kt][r];
+                    if (p.drop_thresh) {
+                        // the hash of query 4 g + r sits in lane (lane & ~3) + r; my key is field (i & 3) of (h1, h2)
+                        const unsigned a1 = r == 0 ? quad_bcast<0>(h1) : r == 1 ? quad_bcast<1>(h1) : r == 2 ? quad_bcast<2>(h1) : quad_bcast<3>(h1);
+                        const unsigned a2 = r == 0 ? quad_bcast<0>(h2) : r == 1 ? quad_bcast<1>(h2) : r == 2 ? quad_bcast<2>(h2) : quad_bcast<3>(h2);
+                        const unsigned hh = (i & 2) ? a2 : a1;
+                        const bool keep = ((i & 1) ? (hh >> 16) : (hh & 0xFFFFu)) >= p.drop_thresh;
+                        pk = keep ? pr * p.drop_inv : 0.f;
+                        dpe = keep ? dpe * p.drop_inv : 0.f;
+                    }
+                    pd[r] = pk;
+                    dsv[r] = pr * (dpe - de[r]);               // the 1/sqrt(d) factor: folded into K^T (dQ) and into the dK^T epilogue
+                }
+                s[qt][kt] = (f32x4){pd[0], pd[1], pd[2], pd[3]};
+                dp[qt][kt] = (f32x4){dsv[0], dsv[1], dsv[2], dsv[3]};
+                store4<T>(reinterpret_cast<T*>(dsb + (t & 1) * KR_DS + qt * (KR_KEYS * 32) + ds_w[kt]), dsv);
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            frag_from_acc(pf[kt], s[0][kt], s[1][kt]);           // k = query: elements 0-3 <- q 4g.., 4-7 <- q 16 + 4g..
+            frag_from_acc(dsf[kt], dp[0][kt], dp[1][kt]);
+        }
+        lds_fence();
+        if (!(p.debug & 4))
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                mma16(dv[dt][kt], doT[dt], pf[kt]);              // dV^T[d][key] += dO^T[d][q] P'[q][key]
+                mma16(dk[dt][kt], qT[dt], dsf[kt]);              // dK^T[d][key] += Q^T[d][q] dS[q][key]
+            }
+        // ---- slice t + 1 has landed (younger: the dQ store of slice t - 2 and the DMA of slice t + 2), then the one barrier
+        {
+            const int younger = (t >= 2 ? 1 : 0) + (t + 2 < nsl ? 1 : 0);
+            if (younger >= 2) wait_vm<2>(); else if (younger == 1) wait_vm<1>(); else wait_vm<0>();
+        }
+        wait_lgkm();
+        __builtin_amdgcn_s_barrier();
+        // ---- dQ rows of slice t - 1 leave (staged in phase B of the previous iteration), the ring slot of slice t - 1 is refilled
+        if (t >= 1 && dq_slabs) {
+            // partial over this key block: f32 slab [kb][b S + q][H] (same program point as the bf16 rows below: the counted
+            // waits above assume ONE store per wave and slice, issued here)
+            float* dst = dq_slabs + ((long)kb * p.B * S + (long)b * S + q0 - KR_QS + my_qt * 16 + i) * H + h * D + my_dt * 16 + 4 * g;
+            *reinterpret_cast<float4*>(dst) = make_float4(dq_prev[0], dq_prev[1], dq_prev[2], dq_prev[3]);
+        }
+        if (t >= 1 && !dq_slabs && !(p.debug & 16)) {
+            const unsigned char* src = dqb + ((t - 1) & 1) * KR_SLICE;
+            const int row = tid >> 4, c8 = tid & 15;                       // 32 rows x 16 chunks of 8 B
+            const uint2 v = ds_read64_asm(lds_off(src + row * 128 + (((c8 >> 1) ^ (row & 7)) * 16) + (c8 & 1) * 8));
+            lds_fence();
+            *reinterpret_cast<uint2*>(dqkv + (long)(q0 - KR_QS + row) * ld + h * D + c8 * 4) = v;
+        }
+        if (t + 3 < nsl) issue_slice(t + 3);
+        // ---- phase B: my dQ^T tile [16 d x 16 q] of slice t over the 256 keys of the block
+        f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(p.debug & 1)) {
+            Frag<T> dst[8];
+            const unsigned base = lds_off(dsb + (t & 1) * KR_DS + ds_r);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) tr_pair_asm<16 * 32>(dst[ks], base + ks * 32 * 32);
+            lds_fence();
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) mma16(dq, ktr[ks], dst[ks]);          // D[d 4g+r][query i]
+        }
+        dq_prev = dq;
+        if (!dq_slabs) {
+            float v[4] = {dq[0], dq[1], dq[2], dq[3]};
+            const int row = my_qt * 16 + i;
+            store4<T>(reinterpret_cast<T*>(dqb + (t & 1) * KR_SLICE + row * 128 + (((2 * my_dt + (g >> 1)) ^ (row & 7)) * 16) + (g & 1) * 8), v);
+        }
+    }
+    // ---- epilogue: the last dQ slice, then dK^T / dV^T
+    wait_lgkm();
+    __builtin_amdgcn_s_barrier();
+    if (dq_slabs) {
+        float* dst = dq_slabs + ((long)kb * p.B * S + (long)b * S + (nsl - 1) * KR_QS + my_qt * 16 + i) * H + h * D + my_dt * 16 + 4 * g;
+        *reinterpret_cast<float4*>(dst) = make_float4(dq_prev[0], dq_prev[1], dq_prev[2], dq_prev[3]);
+    }
+    if (!dq_slabs) {
+        const unsigned char* src = dqb + ((nsl - 1) & 1) * KR_SLICE;
+        const int row = tid >> 4, c8 = tid & 15;
+        const uint2 v = *reinterpret_cast<const uint2*>(src + row * 128 + (((c8 >> 1) ^ (row & 7)) * 16) + (c8 & 1) * 8);
+        *reinterpret_cast<uint2*>(dqkv + (long)((nsl - 1) * KR_QS + row) * ld + h * D + c8 * 4) = v;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const long key = key0 + wid * 32 + kt * 16 + i;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float a[4] = {dk[dt][kt][0] * p.scale, dk[dt][kt][1] * p.scale, dk[dt][kt][2] * p.scale, dk[dt][kt][3] * p.scale};
+            float c[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            store4<T>(dqkv + key * ld + H + h * D + dt * 16 + 4 * g, a);
+            store4<T>(dqkv + key * ld + 2 * H + h * D + dt * 16 + 4 * g, c);
+        }
+    }
+}
+
+// dQ = sum over the key blocks of their f32 slabs, in block order (S > 256)
+__global__ __launch_bounds__(256) void attn_bwd_dq_finish_kernel(const float* __restrict__ slabs, bf16_t* __restrict__ dqkv,
+                                                                  long rows, int H, int nkb) {
+    const long n4 = rows * (H / 4);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / (H / 4);
+        const int c = (int)(e - row * (H / 4)) * 4;
+        float4 a = *reinterpret_cast<const float4*>(slabs + row * H + c);
+        for (int k = 1; k < nkb; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + ((long)k * rows + row) * H + c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+        store4<bf16_t>(dqkv + row * 3L * H + c, v);
+    }
+}
+
 int check_common(const char* who, int dtype, int B, int S, int A, int hd) {
     POLUS_REQUIRE(dtype == POLUS_F32 || dtype == POLUS_BF16, "%s: bad dtype %d", who, dtype);
     POLUS_REQUIRE(hd == D, "%s: head_dim must be 64 (got %d)", who, hd);
@@ -900,8 +1247,12 @@ extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* ma
     return POLUS_OK;
 }
 
+// delta [B, heads, S] for the two-kernel form; sequences of several 256-key blocks add one f32 dQ slab per block
+// ([S / 256][B S][H], key-resident one-pass backward)
 extern "C" size_t polus_attention_bwd_workspace_bytes(int B, int S, int n_heads) {
-    return (size_t)B * S * n_heads * sizeof(float);
+    size_t n = (size_t)B * S * n_heads * sizeof(float);
+    if (S > KR_KEYS && S % KR_KEYS == 0) n += (size_t)(S / KR_KEYS) * B * S * n_heads * D * sizeof(float);
+    return n;
 }
 
 extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* mask, const void* ctx,
@@ -921,8 +1272,31 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
     a.B = B; a.S = S; a.A = n_heads; a.H = n_heads * D; a.scale = 0.125f;
     POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "polus_attention_bwd: bad drop_p");
     a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p); a.dyn = polus_dyn();
+    a.debug = polus_cfg().attn_debug;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((S + BLK - 1) / BLK, n_heads, B);
+    // Which one-pass form: the key-resident kernel for sequences of several 256-key blocks (S = 512: 117 us against 134 us
+    // for the two-kernel form at B = 16, 12 heads); at S = 256 the query-resident kernel below is faster (16 waves per CU
+    // against 8: 82 us against 90-100 us at B = 64) unless POLUS_ATTN_BWD_KRES=2 forces the key-resident one (tests, A/B).
+    const int kres = polus_cfg().attn_bwd_kres;
+    if (dtype == POLUS_BF16 && polus_cfg().attn_fused && kres && S % KR_KEYS == 0 && S <= 2048 && (S > KR_KEYS || kres >= 2)) {
+        // key-resident one-pass backward: one workgroup per (256-key block, head, batch)
+        const int nkb = S / KR_KEYS;
+        float* slabs = nkb > 1 ? static_cast<float*>(workspace) + (size_t)B * S * n_heads : nullptr;
+        const size_t lds = KR_OFF_STAT + 2 * (size_t)S * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_kres_kernel, dim3(nkb, n_heads, B), dim3(512), lds, st, a, slabs);
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(key-resident)");
+        if (nkb > 1) {
+            hipLaunchKernelGGL(attn_bwd_dq_finish_kernel, dim3(1024), dim3(256), 0, st, slabs, static_cast<bf16_t*>(dqkv), (long)B * S, a.H, nkb);
+            POLUS_CHECK_LAUNCH("polus_attention_bwd(dQ slabs)");
+        }
+        return POLUS_OK;
+    }
     if (dtype == POLUS_BF16 && polus_cfg().attn_fused && (S == 64 || S == 128 || S == 256)) {
         // one pass, one workgroup per (batch, head)
         const size_t lds = 2 * (size_t)S * TileCfg<bf16_t>::RS + 4 * (size_t)KBLK * TileCfg<bf16_t>::RS + 2 * (size_t)S * RSS + (size_t)S * 4;

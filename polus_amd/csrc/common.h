@@ -46,6 +46,8 @@ struct PolusCfg {
     int gemm_order;        // POLUS_GEMM_ORDER: column tiles an XCD's concurrent ping-pong tiles span (0 = row-major run; default 4)
     int reserve_cus;       // POLUS_GEMM_RESERVE_CUS: CUs the tile-shape choice leaves to concurrent RCCL channel kernels (default 0)
     int attn_fwd_dma;      // POLUS_ATTN_FWD_DMA: 1 (default) LDS-DMA / whole-row-softmax attention forward (bf16); 0 = the register-staged kernel
+    int attn_bwd_kres;     // POLUS_ATTN_BWD_KRES: 1 (default) key-resident one-pass attention backward for bf16 sequences of several 256-key blocks, 2 = also at S = 256, 0 = never
+    int attn_debug;        // POLUS_ATTN_DEBUG: diagnostics, parts of the key-resident attention backward switched off (wrong results)
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward for S in {64, 128, 256} (bf16)
 };
 const PolusCfg& polus_cfg();

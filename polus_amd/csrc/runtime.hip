@@ -31,6 +31,8 @@ static void read_cfg() {
     g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
     g_cfg.attn_fused = env_int("POLUS_ATTN_FUSED", 1);
     g_cfg.attn_fwd_dma = env_int("POLUS_ATTN_FWD_DMA", 1);
+    g_cfg.attn_bwd_kres = env_int("POLUS_ATTN_BWD_KRES", 1);
+    g_cfg.attn_debug = env_int("POLUS_ATTN_DEBUG", 0);
     g_cfg.ln_halfwave = env_int("POLUS_LN_HALFWAVE", 1);
     g_cfg.gemm_auto_split = env_int("POLUS_GEMM_AUTO_SPLIT", 1);
     g_cfg.gemm_ring128 = env_int("POLUS_GEMM_RING128", 0);

@@ -195,17 +195,18 @@ def test_c5_bert_base_s512_grad_accum_x4(mode):
 # ------------------------------------------------------------------------------ configs[3]
 def test_c4_bert_large_dual_encoder_s512():
     """configs[3]: BERT-large (L=24, H=1024) dual encoder, S=512, bf16, through
-    EfficientDenseRetrievalTrainer (polus/ir/training.py:47-117).  Per engine: the [CLS] state of one query against
-    the oracle (f32 1e-4, bf16 5e-2 of max|ref|); the encoder arena bit-unchanged by the step (no gradient reaches
-    BERT); the reported loss and the projection gradients against the oracle applied to THAT engine's own [CLS]
-    states (projections -> in-batch scores -> softmax CE on the diagonal).  Across engines: the relative error of
-    the bf16 encoder output.
+    EfficientDenseRetrievalTrainer (polus/ir/training.py:47-117).  Per engine: the [CLS] states of one query and one
+    document against the oracle (f32 1e-4, bf16 5e-2 of max|ref|); the encoder arena bit-unchanged by the step (no
+    gradient reaches BERT); the reported loss and the projection gradients against the oracle applied to THAT engine's
+    own [CLS] states (projections -> in-batch scores -> softmax CE on the diagonal).  End to end: the bf16 engine's loss
+    against the f32 engine's (which the two oracle anchors and its own-state check tie to the oracle at 1e-4).
 
-    What is deliberately not asserted: the gap between the bf16 and the f32 loss.  A random-init BERT-large maps
-    every input to nearly the same [CLS] state, so the 8 x 8 in-batch loss hangs on small differences between them
-    and amplifies the encoder's 1.2e-2 rounding noise: for these very inputs the gap was +0.03, +0.17 and +0.32
-    under three builds whose encoder error is identical (1.23e-2: tools/debug/c4_encoder_err.py) and whose kernels
-    differ only in f32 summation order (LayerNorm kernel, split-K of the N = 1024 GEMMs)."""
+    Conditioning.  With every sequence starting with the same [CLS] token a random-init BERT-large maps all inputs to
+    nearly the same state: the 8 x 8 in-batch loss then hangs on differences the size of the bf16 encoder's 1.2e-2
+    rounding noise, and the bf16-vs-f32 gap read +0.03, +0.17 and +0.32 under three builds with identical encoder error.
+    So the inputs here differ in their first token (the state at position 0 is then input-specific by far more than the
+    noise) and the projections are drawn at sigma = 0.013, which puts the standard deviation of the scores near 2 --
+    inside the range where softmax CE responds to them without saturating.  The end-to-end gap is then asserted."""
     from polus_amd.ir.models import DualEncoder
     from polus_amd.ir.training import ContrastiveLoss, EfficientDenseRetrievalTrainer, InBatchDotScores
     from polus_amd.optimizers import Adam
@@ -213,14 +214,21 @@ def test_c4_bert_large_dual_encoder_s512():
     B, S, E = 8, 512, 128
     qi, qm, _, _ = synth(B, S, 41)
     di, dm, _, _ = synth(B, S, 42)
+    first = np.random.Generator(np.random.PCG64(43)).permutation(np.arange(2000, 2000 + 2 * B)).astype(np.int32)
+    qi[:, 0], di[:, 0] = first[:B], first[B:]                # input-specific first tokens (see Conditioning)
     q = {"input_ids": torch.from_numpy(qi).cuda(), "attention_mask": torch.from_numpy(qm).cuda()}
     d = {"input_ids": torch.from_numpy(di).cuda(), "attention_mask": torch.from_numpy(dm).cuda()}
     ref_cls = ob.bert_fwd(params, ocfg, qi[:1], qm[:1])[1]
+    ref_cls_d = ob.bert_fwd(params, ocfg, di[3:4], dm[3:4])[1]
+    pr = np.random.Generator(np.random.PCG64(44))
+    proj = [pr.standard_normal((E, ocfg.hidden_size)) * 0.013, np.zeros(E), pr.standard_normal((E, ocfg.hidden_size)) * 0.013, np.zeros(E)]
     losses, rel_hidden = {}, {}
     for mode in ("f32", "bf16"):
         enc = build(ocfg, params, None, None, mode, num_labels=None)
         cls = host(enc(**{k: v[:1] for k, v in q.items()}, training=False).pooler_output)
         assert_close(cls, ref_cls, 1e-4 if mode == "f32" else 5e-2, f"[CLS] of query 0 ({mode})")
+        cls_d = host(enc(**{k: v[3:4] for k, v in d.items()}, training=False).pooler_output)
+        assert_close(cls_d, ref_cls_d, 1e-4 if mode == "f32" else 5e-2, f"[CLS] of document 3 ({mode})")
         out_q = enc(**q, training=False)
         hid = out_q.last_hidden_state.float().clone()      # the output lives in the model's scratch: copy before the next forward
         hq = host(out_q.pooler_output).astype(np.float64)
@@ -230,6 +238,8 @@ def test_c4_bert_large_dual_encoder_s512():
         del out_q
         hd = host(enc(**d, training=False).pooler_output).astype(np.float64)
         model = DualEncoder(enc, projection_dim=E, compute_dtype=mode)
+        for v, a in zip(model.trainable_weights, proj):
+            v.assign(a.astype(np.float32))
         w = {v.name: v.numpy().astype(np.float64) for v in model.trainable_weights}
         n = [v.name for v in model.trainable_weights]
         before = enc.arena.params.clone()
@@ -253,4 +263,6 @@ def test_c4_bert_large_dual_encoder_s512():
         del trainer, model, enc
         torch.cuda.empty_cache()
     assert rel_hidden["bf16"] < 2e-2, rel_hidden
-    print(f"c4 first-step loss: f32 {losses['f32']:.4f}  bf16 {losses['bf16']:.4f} (gap not asserted, see the docstring)")
+    print(f"c4 first-step loss: f32 {losses['f32']:.4f}  bf16 {losses['bf16']:.4f}  log(B) {np.log(B):.4f}")
+    assert abs(losses["f32"] - np.log(B)) > 0.05, "scores too small: the in-batch loss would not see the encoders at all"
+    assert abs(losses["bf16"] - losses["f32"]) < 5e-2 * max(1.0, abs(losses["f32"])), losses

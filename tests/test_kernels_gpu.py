@@ -195,22 +195,64 @@ def test_attention_backward_one_pass_equals_two_kernel_form(ops, S, A, drop):
     lse = torch.empty((B, A, S), dtype=torch.float32, device="cuda")
     ops.attention_fwd(qkv_t, mask_t, ctx, lse, B, S, A, drop_p=drop, seed=77)
     outs = []
-    for fused in (1, 0):
-        ops.set_env("POLUS_ATTN_FUSED", fused)
+    ops.set_env("POLUS_ATTN_BWD_KRES", 0)            # the query-resident one-pass kernel (S = 256 would otherwise take the key-resident one)
+    try:
+        for fused in (1, 0):
+            ops.set_env("POLUS_ATTN_FUSED", fused)
+            try:
+                d = torch.full((B * S, 3 * H), float("nan"), dtype=dt, device="cuda")
+                ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d, B, S, A, drop_p=drop, seed=77)
+                outs.append(host(d).reshape(B, S, 3 * H))
+            finally:
+                ops.set_env("POLUS_ATTN_FUSED")
+        for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+            assert_close(outs[0][..., sl], outs[1][..., sl], 1.5e-2, nm)
+        # run-to-run bitwise identical
+        d2 = torch.empty((B * S, 3 * H), dtype=dt, device="cuda")
+        ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d2, B, S, A, drop_p=drop, seed=77)
+        d3 = torch.empty_like(d2)
+        ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d3, B, S, A, drop_p=drop, seed=77)
+        assert torch.equal(d2, d3)
+    finally:
+        ops.set_env("POLUS_ATTN_BWD_KRES")
+
+
+@pytest.mark.parametrize("S,A,B,drop", [(256, 12, 3, 0.0), (256, 2, 2, 0.1), (512, 3, 2, 0.1), (768, 1, 1, 0.2)])
+def test_attention_backward_key_resident_equals_two_kernel_form(ops, S, A, B, drop):
+    """The key-resident one-pass backward (one workgroup per 256-key block; S^T / dP^T with the key on the lane, dK^T and
+    dV^T in registers, dQ through LDS -- or through f32 slabs per key block for S > 256) against the two-kernel form on
+    the same inputs, masks and dropout seed: the SAME dropout mask (the lanes of a key quad exchange their hashes), the
+    same dropped probabilities and dS in bf16, a different summation order only; bitwise reproducible."""
+    H = A * 64
+    qkv, mask, dctx = _attn_case(B, S, A, seed=S + A)
+    dt = torch.bfloat16
+    qkv_t, mask_t, dctx_t = dev(qkv.reshape(B * S, 3 * H), dt), dev(mask), dev(dctx.reshape(B * S, H), dt)
+    ctx = torch.empty((B * S, H), dtype=dt, device="cuda")
+    lse = torch.empty((B, A, S), dtype=torch.float32, device="cuda")
+    ops.attention_fwd(qkv_t, mask_t, ctx, lse, B, S, A, drop_p=drop, seed=77)
+    outs = []
+    for kres in (2, 0):                                   # 2: the key-resident kernel also at S = 256 (it is the default from 512 on)
+        ops.set_env("POLUS_ATTN_BWD_KRES", kres)
+        ops.set_env("POLUS_ATTN_FUSED", 1 if kres else 0)
         try:
             d = torch.full((B * S, 3 * H), float("nan"), dtype=dt, device="cuda")
             ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d, B, S, A, drop_p=drop, seed=77)
             outs.append(host(d).reshape(B, S, 3 * H))
         finally:
+            ops.set_env("POLUS_ATTN_BWD_KRES")
             ops.set_env("POLUS_ATTN_FUSED")
+    assert not np.isnan(outs[0]).any()
     for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         assert_close(outs[0][..., sl], outs[1][..., sl], 1.5e-2, nm)
-    # run-to-run bitwise identical
-    d2 = torch.empty((B * S, 3 * H), dtype=dt, device="cuda")
-    ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d2, B, S, A, drop_p=drop, seed=77)
-    d3 = torch.empty_like(d2)
-    ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d3, B, S, A, drop_p=drop, seed=77)
-    assert torch.equal(d2, d3)
+    ops.set_env("POLUS_ATTN_BWD_KRES", 2)
+    try:
+        d2 = torch.empty((B * S, 3 * H), dtype=dt, device="cuda")
+        ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d2, B, S, A, drop_p=drop, seed=77)
+        d3 = torch.empty_like(d2)
+        ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d3, B, S, A, drop_p=drop, seed=77)
+        assert torch.equal(d2, d3)
+    finally:
+        ops.set_env("POLUS_ATTN_BWD_KRES")
 
 
 def test_attention_no_mask_and_all_masked_row(ops):
