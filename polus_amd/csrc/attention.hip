@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kern
 // The two-kernel form evaluates every score twice (once per orientation of the S x S matrix: ~30 VALU
 // lane-operations per score each time, against 7 matrix products it is VALU time that bounds it); here the
 // second orientation costs an LDS round trip of two bf16 tiles instead.  Atomics-free, fixed summation order.
-constexpr int KBLK = 32, RSS = 80;     // keys per block; row stride of the P' / dS staging tiles (64 B + pad)
+constexpr int KBLK = 32, RSS = 64;     // keys per block; bytes per query of the P' / dS staging tiles: two images (one per 16-key tile) of [S][32 B]
 
 __device__ __forceinline__ void frag_tr_rs(Frag<bf16_t>& f, const unsigned char* tile, int rs, int kb, int c0, int i, int g) {
     const unsigned char* p = tile + (kb + 4 * g + (i >> 2)) * rs + (c0 + 4 * (i & 3)) * 2;
@@ -692,8 +692,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
     unsigned char* Oc = Qc + S * RS;
     unsigned char* Kc = Oc + S * RS;                  // [2][KBLK][RS]
     unsigned char* Vc = Kc + 2 * KBLK * RS;           // [2][KBLK][RS]
-    unsigned char* Ps = Vc + 2 * KBLK * RS;           // [S][RSS]
-    unsigned char* Ds = Ps + S * RSS;                 // [S][RSS]
+    // P' / dS staging: [key tile 0-1][S queries][32 B = 16 keys], 8-byte granule g stored at g ^ ((q >> 2) & 3): the 8-byte
+    // writes of a wave (16 queries x 4 granules) and the transposing reads (8 rows x 32 B) are both conflict-free (80-byte
+    // rows cost a quarter of the LDS cycles of this kernel in bank conflicts: profiles/r02_attention_pmc.txt)
+    unsigned char* Ps = Vc + 2 * KBLK * RS;           // [2][S][32]
+    unsigned char* Ds = Ps + S * RSS;                 // [2][S][32]
     float* kbc = reinterpret_cast<float*>(Ds + S * RSS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b = blockIdx.y;
@@ -779,8 +782,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
                 dsv[r] = pr * (dpe - dl) * p.scale;
                 s[kt][r] = dsv[r];
             }
-            store4<T>(reinterpret_cast<T*>(Ps + q * RSS) + kt * 16 + 4 * g, pd);
-            store4<T>(reinterpret_cast<T*>(Ds + q * RSS) + kt * 16 + 4 * g, dsv);
+            const int st_off = kt * (S * 32) + q * 32 + ((g ^ ((q >> 2) & 3)) * 8);
+            store4<T>(reinterpret_cast<T*>(Ps + st_off), pd);
+            store4<T>(reinterpret_cast<T*>(Ds + st_off), dsv);
         }
         {
             Frag<T> dsb;
@@ -805,7 +809,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
             for (int qs = 0; qs < S / 32; ++qs) {
                 Frag<T> a, bb;
                 frag_tr(a, At, qs * 32, dt * 16, i, g);                  // rows d, k = query
-                frag_tr_rs(bb, Bt, RSS, qs * 32, ktile * 16, i, g);      // k = query (same order), columns = key
+                {   // k = query (same order), columns = the 16 keys of image `ktile`; rows 32 qs + 4 g + (i >> 2) (+16): (row >> 2) & 3 = g
+                    const unsigned char* bp = Bt + ktile * (S * 32) + (qs * 32 + 4 * g + (i >> 2)) * 32 + (((i & 3) ^ g) * 8);
+                    const s16x4 lo = lds_tr16(bp), hi = lds_tr16(bp + 16 * 32);
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bb.v = __builtin_bit_cast(bf16x8, w);
+                }
                 mma16(acc, a, bb);                                        // D[d 4g+r][key i]
             }
             float v[4] = {acc[0], acc[1], acc[2], acc[3]};
