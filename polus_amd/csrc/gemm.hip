@@ -460,6 +460,8 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
     a.ablate = polus_cfg().ablate;
     a.order = polus_cfg().gemm_order;
+    a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_cfg().reserve_cus) : 0;
+    a.persist_all = polus_cfg().gemm_persist >= 2;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
@@ -609,6 +611,8 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     a.colsum_a = cs_ws;
     a.ablate = polus_cfg().ablate;
     a.order = polus_cfg().gemm_order;
+    a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_cfg().reserve_cus) : 0;
+    a.persist_all = polus_cfg().gemm_persist >= 2;
     int rc;
     if (splits_eff > 1) {
         a.C = ws; a.ldc = n_in; a.c_split_stride = (long)n_out * n_in;
@@ -761,6 +765,8 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         a.colsum_a = q.db ? reinterpret_cast<float*>(ws + co[k]) : nullptr;
         a.ablate = ablate;
         a.order = 0;
+        a.persist = 0;
+        a.persist_all = 0;
         if (eff[k] > 1) {
             a.C = ws + so[k]; a.ldc = q.n_in; a.c_split_stride = (long)q.n_out * q.n_in;
             a.epi_vec = a.epi_vec16 = (q.n_in % 4 == 0);

@@ -1,6 +1,7 @@
 // Shared by the MFMA GEMM kernels (gemm.hip: 128x128 general; gemm_ring.hip / gemm_pp.hip / gemm_ppks.hip: bf16
 // direct-to-LDS): launch arguments and the fused epilogues.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace pgemm {
@@ -23,6 +24,8 @@ struct GemmArgs {
     float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
+    int persist_all;  // POLUS_GEMM_PERSIST=2: the persistent form for every multi-round ping-pong launch (A/B)
+    int persist; // gemm_pp.hip: > 0 = number of CUs for the persistent form of multi-round launches (POLUS_GEMM_PERSIST), 0 = one workgroup per tile
     int order;   // gemm_pp.hip: column tiles the concurrent tiles of one XCD span (0 = its run in row-major order)
     const PolusDyn* dyn;  // per-step scalars in device memory (graph replay) or null: kernels with a dropout epilogue
                           // replace drop_seed by polus_eff_seed(drop_seed, dyn) on entry
@@ -232,7 +235,7 @@ template <bool AGPR> __device__ __forceinline__ f32x4 acc_take(f32x4& acc) {
 // vmcnt retires in order, a wait for a residual load would also wait for every older C store):
 //   0 = alpha/bias only, 1 = ACT_FWD (+ pre-activation to aux), 2 = residual (+ dropout), 3 = ACT_BWD (aux read)
 // AGPR: the accumulators are pinned to AGPRs by inline-asm MFMAs, or live in VGPRs (gemm_ring.hip).
-template <typename TC, int WN, bool DROP, int MODE, bool AGPR>
+template <typename TC, int WN, bool DROP, int MODE, bool AGPR, int DEPTH_ = 0>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8][WN / 16], int mb, int nb,
                                               int lane, unsigned char* lds) {
     typedef bf16_t T;
@@ -275,7 +278,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
     // these rows come from HBM (written a layer or a whole forward pass earlier): with VGPR
     // accumulators (ring kernel, 64 spare registers) the prefetch distance is 4 m-tiles, with AGPR
     // accumulators (persistent kernel, fragments of the next tile live) 1.
-    constexpr int DEPTH = AGPR ? 1 : 4, NBUF = DEPTH + 1;
+    constexpr int DEPTH = DEPTH_ > 0 ? DEPTH_ : (AGPR ? 1 : 4), NBUF = DEPTH + 1;     // DEPTH_: the persistent ping-pong kernel keeps the next tile's row offsets live and has room for 2
     bf16x8_t pre[NBUF][2][PASSES];
     auto fetch = [&](int mt, bf16x8_t (&dst)[2][PASSES]) {
         const T* base = has_resid ? resid : static_cast<const T*>(aux);

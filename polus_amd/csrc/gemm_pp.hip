@@ -226,6 +226,185 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
                                              smem + wid * ((EpiDbCfg<WN>::BYTES + 255) / 256 * 256));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form for launches of several rounds (K = 768 with N = 2304 / 3072: three tiles per CU).  Same main loop;
+// one workgroup per CU walks its tiles (those the hardware would have dealt to that CU: index + k x grid), and the
+// operand prologue of the NEXT tile -- all of its K-tile 0 and three quarters of K-tile 1, what a fresh workgroup waits
+// for before its first MFMA -- is issued BEFORE the epilogue of the current one: both operand stages are dead by then,
+// so the 2-3 us of L2 / Infinity-Cache latency pass under the epilogue's stores instead of in front of the next tile.
+// The epilogue therefore cannot stage C in the operand stages: it uses pgemm::epilogue_wave (one half-m-tile buffer per
+// wave, 8 x 2.4 KiB behind the two stages) -- same arithmetic, same operation order, bit-identical results.
+template <int NT> struct PPPCfg {
+    static constexpr int WN = 16 * NT;
+    static constexpr int EPI = (EpiCfg<WN>::BYTES + 255) / 256 * 256;
+    static constexpr int SMEM = PPCfg<NT>::SMEM + 8 * EPI;
+    static_assert(SMEM <= 160 * 1024, "two operand stages + the C staging of the 8 waves in one CU's LDS");
+};
+
+template <int NT, bool DROP, int MODE>
+__global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
+    typedef PPCfg<NT> C;
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    constexpr int WN = C::WN, TN = C::TN, NB = C::NB, STAGE = C::STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const int ntiles = ((p.M + TM - 1) / TM) * tiles_n;
+    const int nk = p.K / TK;
+
+    const int lrow = lane >> 3;
+    const bf16_t* a_src;
+    const bf16_t* b_src;
+    {
+        const int ar = wm * 128 + 8 * wn + lrow;
+        a_src = static_cast<const bf16_t*>(p.A) + ((lane & 7) ^ ((ar >> 1) & 7)) * 8;
+        const int br = 8 * wid + lrow;
+        b_src = static_cast<const bf16_t*>(p.B) + ((lane & 7) ^ ((br >> 1) & 7)) * 8;
+    }
+    long a_rowofs[4], b_rowofs[NB];
+    auto set_tile = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_rowofs[q] = (long)min(m0 + wm * 128 + 32 * q + 8 * wn + lrow, p.M - 1) * p.lda;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) b_rowofs[b] = (long)min(n0 + 64 * b + 8 * wid + lrow, p.N - 1) * p.ldb;
+    };
+    const int a_dst = (wm * 128 + 8 * wn) * 128;
+    const int b_dst = A_REGION + (8 * wid) * 128;
+    auto load_a = [&](int tile, int q) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src + a_rowofs[q] + (long)tile * TK),
+                                         (lds_void_t*)(smem + (tile & 1) * STAGE + a_dst + q * 4096), 16, 0, 0);
+    };
+    auto load_b = [&](int tile, int b) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(b_src + b_rowofs[b] + (long)tile * TK),
+                                         (lds_void_t*)(smem + (tile & 1) * STAGE + b_dst + b * 8192), 16, 0, 0);
+    };
+    auto issue_prologue = [&]() {          // all of K-tile 0, then what phases 1-3 of "K-tile -1" would have issued for K-tile 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_a(0, q);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) load_b(0, b);
+        if (nk > 1) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { load_a(1, q); load_b(1, q); }
+        }
+    };
+    const int swz = (i >> 1) & 7;
+    const int c0 = (g ^ swz) * 16, c1 = ((4 + g) ^ swz) * 16;
+    const int a_off = (wm * 128 + i) * 128;
+    const int b_off = A_REGION + (wn * WN + i) * 128;
+
+    int it = blockIdx.x, trow, tcol;
+    tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
+    int m0 = trow * TM, n0 = tcol * TN;
+    set_tile(m0, n0);
+    issue_prologue();
+
+    for (; it < ntiles; it += gridDim.x) {
+        f32x4 acc[8][NT];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        Frag<bf16_t> bfr[NT][2], af[2][2];
+        auto read_a = [&](int tile, int slab, int m) {
+            const unsigned char* st = smem + (tile & 1) * STAGE + a_off + (2 * slab + m) * 2048;
+            af[m][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
+            af[m][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
+        };
+        auto read_b = [&](int tile, int nt) {
+            const unsigned char* st = smem + (tile & 1) * STAGE + b_off + nt * 2048;
+            bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
+            bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
+        };
+        // the prologue of this tile was issued before the previous epilogue (or above): everything older than it is done too
+        if (nk > 1 && it == (int)blockIdx.x) vmcnt<6>(); else vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
+
+        auto phase = [&](auto P_, auto TAIL_, int t) {
+            constexpr int P = decltype(P_)::value, TAIL = decltype(TAIL_)::value;
+            __builtin_amdgcn_s_setprio(2);
+            if (P == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) read_b(t, nt);
+            }
+            read_a(t, P, 0);
+            read_a(t, P, 1);
+            if (P == 0 && TAIL <= 1) { load_a(t + 1, 3); if (NB == 4) load_b(t + 1, 3); }
+            if (P >= 1 && TAIL == 0) { load_a(t + 2, P - 1); load_b(t + 2, P - 1); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (P == 3) {
+                if (TAIL == 0) vmcnt<6>(); else vmcnt<0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    mma16(acc[2 * P + m][nt], bfr[nt][0], af[m][0]);
+                    mma16(acc[2 * P + m][nt], bfr[nt][1], af[m][1]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto ktile = [&](auto TAIL_, int t) {
+            phase(std::integral_constant<int, 0>{}, TAIL_, t);
+            phase(std::integral_constant<int, 1>{}, TAIL_, t);
+            phase(std::integral_constant<int, 2>{}, TAIL_, t);
+            phase(std::integral_constant<int, 3>{}, TAIL_, t);
+        };
+        int t = 0;
+        for (; t + 2 < nk; ++t) ktile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) { ktile(std::integral_constant<int, 1>{}, t); ++t; }
+        ktile(std::integral_constant<int, 2>{}, t);
+        if (wm == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's last barrier (b)
+
+        // every wave is done with both operand stages and no DMA is in flight: the next tile's operands start now
+        const int cm0 = m0, cn0 = n0;
+        // (the epilogue's bias / aux / residual loads are ordinary loads: hipcc waits vmcnt(0) at their first use while LDS-DMA
+        // is in flight, i.e. for the prologue as well.  Issuing the prologue FIRST keeps both in flight together; issuing it
+        // behind the bias loads -- so that the staging reads need not wait for it -- measured 5 % slower on the dU launch)
+        if (it + (int)gridDim.x < ntiles) {
+            tile_of(it + gridDim.x, ntiles, tiles_n, p.order, trow, tcol);
+            m0 = trow * TM; n0 = tcol * TN;
+            set_tile(m0, n0);
+            issue_prologue();
+        }
+        epilogue_wave<bf16_t, WN, DROP, MODE, false, (NT == 4 ? (MODE == 3 || DROP ? 1 : 2) : 4)>(
+            p, acc, cm0 + wm * 128, cn0 + wn * WN, lane, smem + 2 * STAGE + wid * PPPCfg<NT>::EPI);
+    }
+}
+
+template <int NT, bool DROP, int MODE>
+int launch_ppp(const GemmArgs& a, int ncu, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_ppp_kernel<NT, DROP, MODE>;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PPPCfg<NT>::SMEM));
+        attr_done = true;
+    }
+    const int tiles = ((a.M + TM - 1) / TM) * ((a.N + PPCfg<NT>::TN - 1) / PPCfg<NT>::TN);
+    hipLaunchKernelGGL(kern, dim3(tiles < ncu ? tiles : ncu), dim3(NTHR), PPPCfg<NT>::SMEM, st, a);
+    POLUS_CHECK_LAUNCH("polus_gemm(ping-pong 256-wide, persistent)");
+    return POLUS_OK;
+}
+template <int NT>
+int launch_ppp_mode(const GemmArgs& a, int mode, int drop, int ncu, hipStream_t st) {
+    switch (mode) {
+        case 0: return launch_ppp<NT, false, 0>(a, ncu, st);
+        case 1: return launch_ppp<NT, false, 1>(a, ncu, st);
+        case 2: return drop ? launch_ppp<NT, true, 2>(a, ncu, st) : launch_ppp<NT, false, 2>(a, ncu, st);
+        case 3: return launch_ppp<NT, false, 3>(a, ncu, st);
+    }
+    return POLUS_ERR_INVALID;
+}
+
 template <int NT, bool DROP, int MODE, int ABL = 0>
 int launch_pp(const GemmArgs& a, hipStream_t st) {
     typedef PPCfg<NT> C;
@@ -283,6 +462,17 @@ int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
 // tn = 256 or 192; mode from polus_gemm_epi_mode (>= 0); K % 64 == 0; bf16 C; 16-byte aligned rows.
 int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStream_t st) {
     if (mode < 0 || a.K % TK != 0 || a.K < TK) return POLUS_ERR_INVALID;
+    if (a.persist > 0 && !a.ablate) {
+        // several rounds of tiles: one workgroup per CU walks them, the next tile's operand prologue under the epilogue
+        const int tiles = ((a.M + TM - 1) / TM) * ((a.N + tn - 1) / tn);
+        // measured (tools/pp_bench.py --ab POLUS_GEMM_PERSIST=0,1): wins on the 256-wide GELU launches (FFN1 forward, dU), loses on
+        // the 192-wide bias-only QKV launch, whose epilogue is too short to hide anything; POLUS_GEMM_PERSIST=2 forces it everywhere
+        const bool wins = (tn == 256 && (mode == 1 || mode == 3)) || a.persist_all;
+        if (tiles > a.persist && wins) {
+            if (tn == 256) return launch_ppp_mode<4>(a, mode, drop, a.persist, st);
+            if (tn == 192) return launch_ppp_mode<3>(a, mode, drop, a.persist, st);
+        }
+    }
     if (tn == 256) return launch_pp_mode<4>(a, mode, drop, st);
     if (tn == 192) return launch_pp_mode<3>(a, mode, drop, st);
     return POLUS_ERR_INVALID;

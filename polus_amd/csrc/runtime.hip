@@ -27,6 +27,7 @@ static void read_cfg() {
     g_cfg.ablate = env_int("POLUS_GEMM_ABLATE", 0);
     g_cfg.gemm_order = env_int("POLUS_GEMM_ORDER", 4);
     g_cfg.reserve_cus = env_int("POLUS_GEMM_RESERVE_CUS", 0);
+    g_cfg.gemm_persist = env_int("POLUS_GEMM_PERSIST", 1);
     g_cfg.attn_waves = env_int("POLUS_ATTN_WAVES", 0);
     g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
     g_cfg.attn_fused = env_int("POLUS_ATTN_FUSED", 1);

@@ -670,6 +670,40 @@ def test_dense_bwd_params(ops, dtype, T, n_out, n_in, sk):
 
 
 @pytest.mark.parametrize("tn", [256, 192])
+@pytest.mark.parametrize("M,N,K", [(1024, 3072, 768), (1280, 2304, 320), (1000, 1500, 64)])
+def test_gemm_pingpong_persistent_equals_per_tile(ops, tn, M, N, K):
+    """gemm_ppp_kernel (one workgroup per CU walks several tiles, the next tile's operand prologue issued before the current
+    epilogue) against the one-workgroup-per-tile launch: same MFMA order, same epilogue arithmetic -- bit-identical, for
+    every epilogue mode, odd and even K-tile counts, ragged edges.  POLUS_GEMM_RESERVE_CUS shrinks the grid to 32
+    workgroups so that these small problems take 2-3 tiles each; POLUS_GEMM_PERSIST=2 selects the form for every mode."""
+    r = rng(M + N + K)
+    dt = torch.bfloat16
+    a_t, b_t = dev(r.standard_normal((M, K)), dt), dev(r.standard_normal((N, K)) * 0.1, dt)
+    bias_t, r_t, u_t = dev(r.standard_normal(N), torch.float32), dev(r.standard_normal((M, N)), dt), dev(r.standard_normal((M, N)), dt)
+    cases = [dict(bias=bias_t), dict(bias=bias_t, aux="new", act="gelu", flags=ops.GEMM_ACT_FWD), dict(resid=r_t),
+             dict(bias=bias_t, resid=r_t, drop_p=0.1, seed=11), dict(aux=u_t, act="gelu", flags=ops.GEMM_ACT_BWD)]
+    ops.set_env("POLUS_GEMM_PP", tn)
+    ops.set_env("POLUS_GEMM_RESERVE_CUS", 224)
+    try:
+        for kw in cases:
+            outs = []
+            for pers in (2, 0):
+                ops.set_env("POLUS_GEMM_PERSIST", pers)
+                out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+                kw2 = dict(kw)
+                if kw2.get("aux") == "new":
+                    kw2["aux"] = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
+                ops.gemm(a_t, b_t, out, **kw2)
+                outs.append((out, kw2.get("aux")))
+            assert not torch.isnan(outs[0][0].float()).any()
+            assert torch.equal(outs[0][0], outs[1][0]), sorted(kw)
+            if kw.get("aux") == "new":
+                assert torch.equal(outs[0][1], outs[1][1])
+    finally:
+        ops.set_env("POLUS_GEMM_PP"); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PERSIST")
+
+
+@pytest.mark.parametrize("tn", [256, 192])
 @pytest.mark.parametrize("M,N,K", [(512, 768, 768), (256, 256, 64), (256, 192, 128), (520, 456, 192), (1024, 2304, 320),
                                    (768, 3072, 3072)])
 def test_gemm_pingpong_256wide(ops, tn, M, N, K):
