@@ -826,23 +826,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(AttnArgs p) {
     store_acc_T<T>(dqkv, ld, q, h * D, dq, 1.0f, g, true);
 }
 
-// ---------------------------------------------------------------- backward in one pass, key-resident (bf16, S % 256 == 0)
-// One workgroup = 8 waves = 256 keys of one (batch, head); wave w owns keys 32 w .. 32 w + 31 and keeps their dK^T and
-// dV^T ([64 d x 32 keys] each) in registers while the workgroup sweeps the queries in slices of 32.  Per slice:
-//   A  S = Q K^T and dP = dO V^T with the QUERY on the MFMA row and the key on the lane (K and V rows live in registers
-//      as the column operands); the exponential, the dropout mask and dS once per score; the dropped probabilities P'
-//      and dS are then ALREADY the column operands of dV^T += dO^T P' and dK^T += Q^T dS (contraction over the slice's
-//      queries), so neither crosses LDS; only dS does, once, as bf16 [key][query];
-//   B  dQ^T of the slice ([64 d x 32 q] = 8 tiles, one per wave) over all 256 keys: K^T fragments (registers, loaded
-//      once) x dS^T (transposing LDS reads) -- final for this key block, no sum across waves.
-// One barrier per slice: dS is double-buffered, dQ tiles are staged in LDS and leave as whole 128-byte rows one slice
-// later.  Q and dO slices come by LDS-DMA two to three slices ahead behind counted waits (every transposing read is
-// inline asm: the compiler would otherwise drain the prefetch with vmcnt(0) before each of them).
-// Sequences longer than 256 keys take one workgroup per 256-key block: dK / dV are still final per workgroup; the dQ
-// tiles go to an f32 slab per key block and attn_bwd_dq_finish_kernel adds the slabs in block order.
-// The dropout mask is indexed ((b A + h) S + q) S + key with one hash per FOUR CONSECUTIVE KEYS; here a lane holds four
-// queries of one key, so each lane hashes the quad of ONE of its queries and the four lanes of a key quad exchange the
-// hashes by DPP -- the mask is bit-identical to the forward's.
+// ---- inline-asm LDS reads (invisible to the compiler's LDS-DMA alias waits) and a DPP quad broadcast
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned lds_off(const unsigned char* p) { return (unsigned)(unsigned long)(const lds_u8*)p; }
@@ -875,6 +859,225 @@ template <int R> __device__ __forceinline__ unsigned quad_bcast(unsigned v) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, R | (R << 2) | (R << 4) | (R << 6), 0xF, 0xF, true);
 }
 
+
+// ---------------------------------------------------------------- backward in ONE pass, query-resident, 64-key blocks + LDS-DMA
+// Same decomposition as attn_bwd_fused_kernel (one workgroup per (batch, head), S / 16 waves, phase 1 = scores, dS and dQ
+// of the wave's 16 queries, phase 2 = the block's dK^T / dV^T tiles over all queries), rebuilt around what bounds that kernel
+// -- two barriers and a register-staged global load per 32 keys, four LDS operand reads per phase-2 MFMA:
+//   * key blocks of 64: half the barriers, phase 2 gives each wave tiles that SHARE their A operand (Q^T or dO^T), three
+//     operand reads per MFMA instead of four;
+//   * Q / dO images, K / V blocks by LDS-DMA into packed 128-byte rows (chunk-XOR swizzle on the source address, as in the
+//     forward kernel); the K / V block is single-buffered: phase 2 does not read it, so block kb + 1 is issued right behind
+//     the barrier that ends phase 1 and lands under phase 2 (every LDS read in here is inline asm -- a compiler-visible
+//     read would be preceded by vmcnt(0), i.e. by the landing of the DMA just issued);
+//   * P' / dS staging: four images (one per 16-key tile) of [S][32 B], conflict-free both ways.
+// Arithmetic per score, dropout mask and summation order over the queries are those of attn_bwd_fused_kernel; dQ sums the
+// keys in the same order as well: results are bit-identical to it.
+constexpr int Q64_KB = 64;
+template <int NW> struct Q64Cfg {
+    static constexpr int S = 16 * NW;
+    static constexpr int OFF_O = S * 128, OFF_K = 2 * S * 128, OFF_V = OFF_K + Q64_KB * 128, OFF_P = OFF_V + Q64_KB * 128,
+                         OFF_D = OFF_P + 4 * S * 32, OFF_B = OFF_D + 4 * S * 32, SMEM = OFF_B + S * 4;
+};
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void attn_bwd_q64_kernel(AttnArgs p) {
+    typedef bf16_t T;
+    typedef Q64Cfg<NW> C;
+    constexpr int S = C::S, NT = 64 * NW, NKB = S / Q64_KB;
+    constexpr int KVP = 16 / NW;                       // K / V pieces (8 rows x 128 B) per wave and block
+    constexpr int COMBOS = NW >= 8 ? 1 : 8 / NW;       // (dK | dV, d-tile) pairs per wave in phase 2
+    constexpr int KTW = NW == 16 ? 2 : 4;              // key tiles (of 16) per pair and wave
+    if (p.drop_thresh) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Qi = smem;
+    unsigned char* Oi = smem + C::OFF_O;
+    unsigned char* Kb = smem + C::OFF_K;
+    unsigned char* Vb = smem + C::OFF_V;
+    unsigned char* Ps = smem + C::OFF_P;               // [4][S][32]
+    unsigned char* Ds = smem + C::OFF_D;
+    float* kbc = reinterpret_cast<float*>(smem + C::OFF_B);
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int H = p.H;
+    const long ld = 3L * H;
+    const T* qkv = static_cast<const T*>(p.qkv) + (long)b * S * ld;
+    const T* dctx = static_cast<const T*>(p.dctx) + (long)b * S * H;
+    T* dqkv = static_cast<T*>(p.dqkv) + (long)b * S * ld;
+    const int q = wid * 16 + i;
+    const int r8 = lane >> 3, src_chunk = ((lane & 7) ^ r8) * 8;
+
+    auto issue_kv = [&](int kb) {
+#pragma unroll
+        for (int e = 0; e < KVP; ++e) {
+            const int piece = wid + e * NW;            // 0-7: K rows, 8-15: V rows
+            const long row = (long)(kb * Q64_KB + (piece & 7) * 8 + r8) * ld + h * D + src_chunk;
+            dma16(qkv + row + (piece < 8 ? H : 2 * H), (piece < 8 ? Kb : Vb) + (piece & 7) * 1024);
+        }
+    };
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                      // Q and dO images: 2 NW pieces each, two per wave
+        const int piece = wid + e * NW;
+        dma16(qkv + (long)(piece * 8 + r8) * ld + h * D + src_chunk, Qi + piece * 1024);
+        dma16(dctx + (long)(piece * 8 + r8) * H + h * D + src_chunk, Oi + piece * 1024);
+    }
+    issue_kv(0);
+    if (tid < S) kbc[tid] = key_bias(p.mask, b, S, tid) * LOG2E;
+    const long stat = ((long)b * p.A + h) * S + q;
+    const float lse2 = p.lse[stat] * LOG2E;
+    const float scale2 = p.scale * LOG2E;
+    Frag<T> of[2];
+    {
+        const T* ctx = static_cast<const T*>(p.ctx) + (long)b * S * H;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) frag_global<T>(of[sub], ctx + (long)q * H + h * D + sub * 32 + 8 * g, true);
+    }
+    wait_vm<0>();
+    wait_lgkm();
+    __builtin_amdgcn_s_barrier();
+    const int qoff0 = q * 128 + ((g ^ (q & 7)) * 16), qoff1 = q * 128 + (((4 + g) ^ (q & 7)) * 16);
+    float dl = 0.f;                                    // delta = rowsum(dO * O) of this query's head
+    {
+        Frag<T> dof[2];
+        ds_read128_asm(dof[0], lds_off(Oi + qoff0));
+        ds_read128_asm(dof[1], lds_off(Oi + qoff1));
+        lds_fence();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of[sub].v[j] * (float)dof[sub].v[j];
+        dl = col_sum(dl);
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // lane constants of the LDS reads (packed 128-byte rows, chunk c of row r at c ^ (r & 7))
+    const int rr0 = i * 128 + ((g ^ (i & 7)) * 16), rr1 = i * 128 + (((4 + g) ^ (i & 7)) * 16);   // rows 16 kt + i, d-chunk 4 sub + g
+    const int trow = 4 * g + (i >> 2), tx = trow & 7, thalf = (i & 1) * 8, tc = (i & 3) >> 1;    // transposing reads
+    const int st_w = q * 32 + ((g ^ ((q >> 2) & 3)) * 8);                                        // staging write: image kt, row q
+    const int st_r = trow * 32 + (((i & 3) ^ g) * 8);                                            // staging read: rows 32 qs + trow (+16)
+
+    for (int kb = 0; kb < NKB; ++kb) {
+        // ---- phase 1: my 16 queries x the 64 keys of the block (the query-side fragments are re-read from the resident images
+        // every block: 16 registers that need not stay live across phase 2)
+        f32x4 s[4];
+        Frag<T> qf[2], dof[2];
+        ds_read128_asm(qf[0], lds_off(Qi + qoff0));
+        ds_read128_asm(qf[1], lds_off(Qi + qoff1));
+        ds_read128_asm(dof[0], lds_off(Oi + qoff0));
+        ds_read128_asm(dof[1], lds_off(Oi + qoff1));
+        const unsigned rowb = (((unsigned)b * p.A + h) * S + (unsigned)q) * S + kb * Q64_KB + 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {                        // one key tile at a time: its dP tile dies in the element-wise part
+            Frag<T> ka[2], va[2];
+            ds_read128_asm(ka[0], lds_off(Kb + kt * 2048 + rr0));
+            ds_read128_asm(ka[1], lds_off(Kb + kt * 2048 + rr1));
+            ds_read128_asm(va[0], lds_off(Vb + kt * 2048 + rr0));
+            ds_read128_asm(va[1], lds_off(Vb + kt * 2048 + rr1));
+            lds_fence();
+            f32x4 dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            mma16(s[kt], ka[0], qf[0]);                         // D[key 4g+r][query i]
+            mma16(s[kt], ka[1], qf[1]);
+            mma16(dp, va[0], dof[0]);
+            mma16(dp, va[1], dof[1]);
+            float pd[4], dsv[4];
+            bool keep[4] = {true, true, true, true};
+            if (p.drop_thresh) polus_keep4(p.drop_seed, rowb + kt * 16, p.drop_thresh, keep);
+            const f32x4 kbv = *reinterpret_cast<const f32x4*>(kbc + kb * Q64_KB + kt * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale2, kbv[r]) - lse2);
+                const float pk = keep[r] ? pr * p.drop_inv : 0.f;             // dropped P: what multiplied V forward
+                const float dpe = keep[r] ? dp[r] * p.drop_inv : 0.f;
+                pd[r] = pk;
+                dsv[r] = pr * (dpe - dl) * p.scale;
+                s[kt][r] = dsv[r];
+            }
+            store4<T>(reinterpret_cast<T*>(Ps + kt * (S * 32) + st_w), pd);
+            store4<T>(reinterpret_cast<T*>(Ds + kt * (S * 32) + st_w), dsv);
+        }
+        {   // dQ^T += K^T dS^T over the 64 keys: K^T fragments by transposing reads, dS^T from the registers
+            Frag<T> kT[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    tr_pair_asm<16 * 128>(kT[ks][dt], lds_off(Kb + (ks * 32 + trow) * 128 + (((2 * dt + tc) ^ tx) * 16) + thalf));
+            lds_fence();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<T> dsb;
+                frag_from_acc(dsb, s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) mma16(dq[dt], kT[ks][dt], dsb);  // D[d][query]
+            }
+        }
+        wait_lgkm();
+        __builtin_amdgcn_s_barrier();
+        // ---- the next block's K / V land under phase 2 (which reads neither)
+        if (kb + 1 < NKB) issue_kv(kb + 1);
+        // ---- phase 2: this block's dK^T / dV^T tiles over ALL queries; a wave's tiles share the A operand (Q^T or dO^T)
+#pragma unroll
+        for (int c = 0; c < COMBOS; ++c) {
+            const int combo = NW == 16 ? (wid >> 1) : wid * COMBOS + c;       // type = combo >> 2 (0: dK, 1: dV), d-tile = combo & 3
+            const int type = combo >> 2, dt = combo & 3, kt0 = NW == 16 ? (wid & 1) * 2 : 0;
+            const unsigned char* At = type ? Oi : Qi;
+            const unsigned char* Bt = type ? Ps : Ds;
+            constexpr int QH = (S / 32) < 4 ? (S / 32) : 4;                     // query k-steps (of 32) per pass: 4 A + 4 B fragments in flight
+            f32x4 acc[KTW];
+#pragma unroll
+            for (int k2 = 0; k2 < KTW; ++k2) acc[k2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q0 = 0; q0 < S / 32; q0 += QH) {
+                Frag<T> af[QH];
+#pragma unroll
+                for (int qs = 0; qs < QH; ++qs)
+                    tr_pair_asm<16 * 128>(af[qs], lds_off(At + ((q0 + qs) * 32 + trow) * 128 + (((2 * dt + tc) ^ tx) * 16) + thalf));
+#pragma unroll
+                for (int k2 = 0; k2 < KTW; ++k2) {
+                    Frag<T> bf[QH];
+#pragma unroll
+                    for (int qs = 0; qs < QH; ++qs)
+                        tr_pair_asm<16 * 32>(bf[qs], lds_off(Bt + (kt0 + k2) * (S * 32) + (q0 + qs) * 32 * 32 + st_r));
+                    lds_fence();
+#pragma unroll
+                    for (int qs = 0; qs < QH; ++qs) mma16(acc[k2], af[qs], bf[qs]);      // D[d 4g+r][key i]
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < KTW; ++k2) {
+                float v[4] = {acc[k2][0], acc[k2][1], acc[k2][2], acc[k2][3]};
+                store4<T>(dqkv + (long)(kb * Q64_KB + (kt0 + k2) * 16 + i) * ld + (type ? 2 * H : H) + h * D + dt * 16 + 4 * g, v);
+            }
+        }
+        // ---- block kb + 1 has landed (younger: this phase's COMBOS x KTW tile stores), every wave is done with the staging images
+        if (kb + 1 < NKB) wait_vm<COMBOS * KTW>();
+        wait_lgkm();
+        __builtin_amdgcn_s_barrier();
+    }
+    store_acc_T<T>(dqkv, ld, q, h * D, dq, 1.0f, g, true);
+}
+
+// ---------------------------------------------------------------- backward in one pass, key-resident (bf16, S % 256 == 0)
+// One workgroup = 8 waves = 256 keys of one (batch, head); wave w owns keys 32 w .. 32 w + 31 and keeps their dK^T and
+// dV^T ([64 d x 32 keys] each) in registers while the workgroup sweeps the queries in slices of 32.  Per slice:
+//   A  S = Q K^T and dP = dO V^T with the QUERY on the MFMA row and the key on the lane (K and V rows live in registers
+//      as the column operands); the exponential, the dropout mask and dS once per score; the dropped probabilities P'
+//      and dS are then ALREADY the column operands of dV^T += dO^T P' and dK^T += Q^T dS (contraction over the slice's
+//      queries), so neither crosses LDS; only dS does, once, as bf16 [key][query];
+//   B  dQ^T of the slice ([64 d x 32 q] = 8 tiles, one per wave) over all 256 keys: K^T fragments (registers, loaded
+//      once) x dS^T (transposing LDS reads) -- final for this key block, no sum across waves.
+// One barrier per slice: dS is double-buffered, dQ tiles are staged in LDS and leave as whole 128-byte rows one slice
+// later.  Q and dO slices come by LDS-DMA two to three slices ahead behind counted waits (every transposing read is
+// inline asm: the compiler would otherwise drain the prefetch with vmcnt(0) before each of them).
+// Sequences longer than 256 keys take one workgroup per 256-key block: dK / dV are still final per workgroup; the dQ
+// tiles go to an f32 slab per key block and attn_bwd_dq_finish_kernel adds the slabs in block order.
+// The dropout mask is indexed ((b A + h) S + q) S + key with one hash per FOUR CONSECUTIVE KEYS; here a lane holds four
+// queries of one key, so each lane hashes the quad of ONE of its queries and the four lanes of a key quad exchange the
+// hashes by DPP -- the mask is bit-identical to the forward's.
 constexpr int KR_KEYS = 256, KR_QS = 32, KR_RING = 4;
 constexpr int KR_KV = KR_KEYS * 128;                 // K image / V image
 constexpr int KR_SLICE = KR_QS * 128;                // a 32-query slice of Q or of dO
@@ -1214,6 +1417,17 @@ int launch_fwd_dma(const AttnArgs& a, hipStream_t st) {
     return POLUS_OK;
 }
 template <int NW>
+int launch_q64(const AttnArgs& a, int n_heads, int B, hipStream_t st) {
+    auto kern = attn_bwd_q64_kernel<NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q64Cfg<NW>::SMEM));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_heads, B), dim3(64 * NW), Q64Cfg<NW>::SMEM, st, a);
+    return POLUS_OK;
+}
+template <int NW>
 int launch_fused(const AttnArgs& a, int n_heads, int B, size_t lds, hipStream_t st) {
     auto kern = attn_bwd_fused_kernel<NW>;
     static bool attr_done = false;
@@ -1305,6 +1519,16 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
             hipLaunchKernelGGL(attn_bwd_dq_finish_kernel, dim3(1024), dim3(256), 0, st, slabs, static_cast<bf16_t*>(dqkv), (long)B * S, a.H, nkb);
             POLUS_CHECK_LAUNCH("polus_attention_bwd(dQ slabs)");
         }
+        return POLUS_OK;
+    }
+    // query-resident one-pass forms: 64-key blocks by LDS-DMA at S = 256 (80.5 -> 76.8 us at 64 x 256, bit-identical), the 32-key-block
+    // kernel at S = 64 / 128 (20.9 against 22.5 us at 32 x 128); POLUS_ATTN_FUSED = 2 / 3 forces the former / the latter
+    const int fused = polus_cfg().attn_fused;
+    if (dtype == POLUS_BF16 && (fused == 2 || (fused == 1 && S == 256)) && (S == 64 || S == 128 || S == 256)) {
+        // one pass, one workgroup per (batch, head), 64-key blocks by LDS-DMA
+        int rc2 = S == 256 ? launch_q64<16>(a, n_heads, B, st) : S == 128 ? launch_q64<8>(a, n_heads, B, st) : launch_q64<4>(a, n_heads, B, st);
+        if (rc2 != POLUS_OK) return rc2;
+        POLUS_CHECK_LAUNCH("polus_attention_bwd(one pass, 64-key blocks)");
         return POLUS_OK;
     }
     if (dtype == POLUS_BF16 && polus_cfg().attn_fused && (S == 64 || S == 128 || S == 256)) {

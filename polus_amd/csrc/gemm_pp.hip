@@ -297,6 +297,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
     const int b_off = A_REGION + (wn * WN + i) * 128;
 
     int it = blockIdx.x, trow, tcol;
+    bool prev_interior = false;
     tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
     int m0 = trow * TM, n0 = tcol * TN;
     set_tile(m0, n0);
@@ -319,8 +320,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
             bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
             bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
         };
-        // the prologue of this tile was issued before the previous epilogue (or above): everything older than it is done too
-        if (nk > 1 && it == (int)blockIdx.x) vmcnt<6>(); else vmcnt<0>();
+        // The prologue of this tile was issued before the previous tile's epilogue, whose stores are YOUNGER: an interior
+        // epilogue issues at least EPI_STORES vector-memory operations behind it (its C -- and pre-activation -- stores; the bias /
+        // aux / residual loads come on top), so "all but the EPI_STORES youngest" covers the prologue and lets the store tail
+        // drain under this tile's first K-tile instead of in front of it.  (Fewer younger operations than assumed would make the
+        // wait stricter, never laxer; an edge tile's epilogue has another count: full drain.)
+        constexpr int EPI_STORES = (MODE == 1 ? 2 : 1) * 16 * EpiCfg<WN>::PASSES;
+        if (it == (int)blockIdx.x) { if (nk > 1) vmcnt<6>(); else vmcnt<0>(); }
+        else if (prev_interior && !(p.ablate & 128)) vmcnt<(EPI_STORES < 60 ? EPI_STORES : 60)>();
+        else vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
 
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
 
         // every wave is done with both operand stages and no DMA is in flight: the next tile's operands start now
         const int cm0 = m0, cn0 = n0;
+        prev_interior = p.epi_vec16 && (cm0 + TM <= p.M) && (cn0 + TN <= p.N);
         // (the epilogue's bias / aux / residual loads are ordinary loads: hipcc waits vmcnt(0) at their first use while LDS-DMA
         // is in flight, i.e. for the prologue as well.  Issuing the prologue FIRST keeps both in flight together; issuing it
         // behind the bias loads -- so that the staging reads need not wait for it -- measured 5 % slower on the dU launch)
@@ -462,7 +471,7 @@ int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
 // tn = 256 or 192; mode from polus_gemm_epi_mode (>= 0); K % 64 == 0; bf16 C; 16-byte aligned rows.
 int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStream_t st) {
     if (mode < 0 || a.K % TK != 0 || a.K < TK) return POLUS_ERR_INVALID;
-    if (a.persist > 0 && !a.ablate) {
+    if (a.persist > 0 && !(a.ablate & 127)) {
         // several rounds of tiles: one workgroup per CU walks them, the next tile's operand prologue under the epilogue
         const int tiles = ((a.M + TM - 1) / TM) * ((a.N + tn - 1) / tn);
         // measured (tools/pp_bench.py --ab POLUS_GEMM_PERSIST=0,1): wins on the 256-wide GELU launches (FFN1 forward, dU), loses on

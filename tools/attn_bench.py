@@ -38,7 +38,11 @@ for p in (0.0, 0.1):
     ops.set_env("POLUS_ATTN_BWD_KRES", 2)
     tb = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
     ops.set_env("POLUS_ATTN_BWD_KRES", 0)
+    ops.set_env("POLUS_ATTN_FUSED", 3)
     tq = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
+    ops.set_env("POLUS_ATTN_FUSED", 2)
+    t64 = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20) if S in (64, 128, 256) else float("nan")
+    ops.set_env("POLUS_ATTN_FUSED")
     ops.set_env("POLUS_ATTN_BWD_KRES")
     t2 = None
     if S in (64, 128, 256):
@@ -47,4 +51,4 @@ for p in (0.0, 0.1):
         ops.set_env("POLUS_ATTN_FUSED")
     med = lambda x: sorted(x)[len(x) // 2] * 1e6
     print(f"B={B} S={S} drop_p={p}: fwd LDS-DMA {med(t[1]):.1f} us (min {min(t[1])*1e6:.1f})  register-staged {med(t[0]):.1f} us   "
-          f"|ctx diff| {dc:.2e} |lse diff| {dl:.2e}   bwd key-resident {tb*1e6:.1f} us (POLUS_ATTN_BWD_KRES=0: {tq*1e6:.1f} us)" + (f"   bwd two kernels {t2*1e6:.1f} us" if t2 else ""), flush=True)
+          f"|ctx diff| {dc:.2e} |lse diff| {dl:.2e}   bwd key-resident {tb*1e6:.1f} us (query-resident, 32-key blocks: {tq*1e6:.1f} us; 64-key blocks: {t64*1e6:.1f} us)" + (f"   bwd two kernels {t2*1e6:.1f} us" if t2 else ""), flush=True)
