@@ -15,8 +15,8 @@ import sys
 
 
 def is_kc_gemm(name):
-    # gemm_ring_kernel<bf16, A K-contig, B K-contig, *> and every gemm_p_kernel (bf16 only)
-    return "gemm_pp_kernel" in name or "gemm_p_kernel" in name or "gemm_ring_kernelIDF16bLb0ELb0E" in name
+    # the ping-pong kernels (per-tile and persistent form) and gemm_ring_kernel<bf16, A K-contig, B K-contig, *>
+    return "gemm_pp_kernel" in name or "gemm_ppp_kernel" in name or "gemm_ring_kernelIDF16bLb0ELb0E" in name
 
 
 def per_kernel(dirname, counter):
@@ -35,7 +35,7 @@ def main():
     f_kib = sum(sum(v) for v in fetch.values()) / nf
     w_kib = sum(sum(v) for v in write.values()) / nw
     out = {
-        "kernel": "gemm_pp_kernel<256 | 192 wide, *> (and gemm_ring_kernel<bf16, K-contig, K-contig, *> where chosen): forward Dense and dX = dY.W^T",
+        "kernel": "gemm_pp_kernel<256 | 192 wide, *>, its persistent form gemm_ppp_kernel (and gemm_ring_kernel<bf16, K-contig, K-contig, *> where chosen): forward Dense and dX = dY.W^T",
         "launches_counted": nf,
         "per_kernel": {k[:90]: {"launches": len(v), "FETCH_SIZE_KiB": sum(v) / len(v),
                                 "WRITE_SIZE_KiB": sum(write[k]) / len(write[k])} for k, v in fetch.items()},
