@@ -33,6 +33,15 @@ for name, N, K, mode in (("ffn1", 3072, 768, "gelu"), ("du", 3072, 768, "bwd")):
         ev2 = torch.cuda.Event(); ev2.record(side)
         torch.cuda.current_stream().wait_event(ev2)
 
+    def graphed(fn):
+        """The two launches replayed from a captured HIP graph: no host launch latency between them."""
+        fn(); torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            with _lib.pinned_stream():
+                fn()
+        return g_.replay
+
     def timed(fn, iters=8):
         tot = 0.0
         for _ in range(iters):
@@ -44,8 +53,10 @@ for name, N, K, mode in (("ffn1", 3072, 768, "gelu"), ("du", 3072, 768, "bwd")):
         return tot / iters * 1e3
     ops.set_env("POLUS_GEMM_PERSIST", 1); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PP")
     single(); t_single = [timed(single) for _ in range(3)]
+    t_single_g = [timed(graphed(single)) for _ in range(3)]
     ops.set_env("POLUS_GEMM_PERSIST", 2); ops.set_env("POLUS_GEMM_RESERVE_CUS", 128)
     mixed(); t_mixed = [timed(mixed) for _ in range(3)]
+    t_mixed_g = [timed(graphed(mixed)) for _ in range(3)]
     ops.set_env("POLUS_GEMM_PP", 256)
     def same():   # both halves 256-wide: concurrency alone, no shape mix
         ev = torch.cuda.Event(); ev.record(); side.wait_event(ev)
@@ -56,5 +67,7 @@ for name, N, K, mode in (("ffn1", 3072, 768, "gelu"), ("du", 3072, 768, "bwd")):
             ops.gemm(a[h:], b, c[h:], **kw2)
         ev2 = torch.cuda.Event(); ev2.record(side); torch.cuda.current_stream().wait_event(ev2)
     same(); t_same = [timed(same) for _ in range(3)]
+    t_same_g = [timed(graphed(same)) for _ in range(3)]
     ops.set_env("POLUS_GEMM_PERSIST"); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PP")
-    print(f"{name}: single persistent launch {min(t_single):.1f} us   two halves 256 | 192 on two streams {min(t_mixed):.1f} us   two halves 256 | 256 {min(t_same):.1f} us", flush=True)
+    print(f"{name}: single persistent launch {min(t_single):.1f} us (graph replay {min(t_single_g):.1f})   two halves 256 | 192 on two streams {min(t_mixed):.1f} us "
+          f"(graph replay {min(t_mixed_g):.1f})   two halves 256 | 256 {min(t_same):.1f} us (graph replay {min(t_same_g):.1f})", flush=True)
