@@ -44,7 +44,7 @@ struct PolusCfg {
     int gemm_auto_split;   // POLUS_GEMM_AUTO_SPLIT: 1 (default) polus_gemm_auto_split recommends K slices for under-filled bf16 Dense GEMMs; 0 = always 1
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
     int gemm_order;        // POLUS_GEMM_ORDER: column tiles an XCD's concurrent ping-pong tiles span (0 = row-major run; default 4)
-    int gemm_persist;      // POLUS_GEMM_PERSIST: 1 (default) = the multi-round 256-wide GELU launches (FFN1 forward, dU) as one persistent workgroup per CU (next tile's prologue under the epilogue), 2 = every multi-round ping-pong launch, 0 = never
+    int gemm_persist;      // POLUS_GEMM_PERSIST: 1 (default) = the multi-round 256-wide launches as one persistent workgroup per CU (next tile's prologue under the epilogue), 2 = every multi-round ping-pong launch, 0 = never
     int reserve_cus;       // POLUS_GEMM_RESERVE_CUS: CUs the tile-shape choice leaves to concurrent RCCL channel kernels (default 0)
     int attn_fwd_dma;      // POLUS_ATTN_FWD_DMA: 1 (default) LDS-DMA / whole-row-softmax attention forward (bf16); 0 = the register-staged kernel
     int attn_bwd_kres;     // POLUS_ATTN_BWD_KRES: 1 (default) key-resident one-pass attention backward for bf16 sequences of several 256-key blocks, 2 = also at S = 256, 0 = never

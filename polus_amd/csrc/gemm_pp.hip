@@ -474,9 +474,11 @@ int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStrea
     if (a.persist > 0 && !(a.ablate & 127)) {
         // several rounds of tiles: one workgroup per CU walks them, the next tile's operand prologue under the epilogue
         const int tiles = ((a.M + TM - 1) / TM) * ((a.N + tn - 1) / tn);
-        // measured (tools/pp_bench.py --ab POLUS_GEMM_PERSIST=0,1): wins on the 256-wide GELU launches (FFN1 forward, dU), loses on
-        // the 192-wide bias-only QKV launch, whose epilogue is too short to hide anything; POLUS_GEMM_PERSIST=2 forces it everywhere
-        const bool wins = (tn == 256 && (mode == 1 || mode == 3)) || a.persist_all;
+        // measured (tools/pp_bench.py --ab POLUS_GEMM_PERSIST=0,1,2; bench.py --config c3 | c4 | c5): wins on the 256-wide launches --
+        // the GELU ones of BERT-base (FFN1 forward, dU: -8 % from cold caches) and every multi-round launch of BERT-large (+0.5 %
+        // on the c4 step) -- and is neutral to slightly negative on the 192-wide bias-only QKV launch of BERT-base (three exact
+        // rounds, an epilogue too short to hide anything); POLUS_GEMM_PERSIST=2 forces it everywhere
+        const bool wins = tn == 256 || a.persist_all;
         if (tiles > a.persist && wins) {
             if (tn == 256) return launch_ppp_mode<4>(a, mode, drop, a.persist, st);
             if (tn == 192) return launch_ppp_mode<3>(a, mode, drop, a.persist, st);
