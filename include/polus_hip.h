@@ -155,7 +155,11 @@ int polus_attention_bwd(int dtype, const void* qkv, const int32_t* mask, const v
  * bwd: dx; dgamma/dbeta [H] f32 (+= when accumulate); if dbias != NULL also
  *      dbias[H] (+)= column sums of dx (the bias gradient of the Dense that produced x).
  *      When x = dropout(dense) + residual (drop_p > 0, mask index row*H+col as in polus_gemm_dropout):
- *      dx_masked = dx * mask/(1-p) is the gradient the Dense sees, and dbias sums dx_masked. */
+ *      dx_masked = dx * mask/(1-p) is the gradient the Dense sees, and dbias sums dx_masked.
+ *      With dgamma = dbeta = NULL the call stops after the main kernel and leaves the per-workgroup partial sums in
+ *      `workspace` (dbias non-NULL still requests the bias sums); polus_layernorm_bwd_finalize then reduces them -- on any
+ *      stream ordered behind the first call (the training step queues it behind the layer's weight-gradient launch on the
+ *      side stream, off the critical path).  Same kernels in the same order: same bits. */
 size_t polus_layernorm_bwd_workspace_bytes(int rows, int H);
 int polus_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta,
                         void* y, float* mean, float* rstd, int rows, int H, float eps, void* stream);
@@ -164,6 +168,8 @@ int polus_layernorm_bwd(int dtype, const void* dy, const void* x, const float* g
                         float* dgamma, float* dbeta, float* dbias, int accumulate,
                         int rows, int H, void* dx_masked, float drop_p, uint32_t seed,
                         void* workspace, size_t workspace_bytes, void* stream);
+int polus_layernorm_bwd_finalize(void* workspace, size_t workspace_bytes, int rows, int H, float* dgamma, float* dbeta,
+                                 float* dbias, int accumulate, void* stream);
 
 /* ---- embeddings: word[ids] + pos[s] + type[tt] -> LayerNorm (HF TFBertEmbeddings; TF gather
  * has no padding_idx, so row 0 receives its gradient).  Tables and their gradients are f32.

@@ -40,6 +40,7 @@ SIGNATURES = {
     "polus_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "polus_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "polus_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _u32, _vp, _sz, _vp]),
+    "polus_layernorm_bwd_finalize": (_i, [_vp, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "polus_embed_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_embed_ln_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _i, _i, _i, _i, _i, _i, _f, _f, _u32, _vp]),

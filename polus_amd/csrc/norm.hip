@@ -733,7 +733,11 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
                                    float* dgamma, float* dbeta, float* dbias, int accumulate,
                                    int rows, int H, void* dx_masked, float drop_p, uint32_t seed,
                                    void* workspace, size_t workspace_bytes, void* stream) {
-    POLUS_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "polus_layernorm_bwd: null pointer");
+    // dgamma == dbeta == null: leave the per-workgroup partial sums in `workspace` (which the caller then owns until
+    // polus_layernorm_bwd_finalize has run on it, on any stream ordered behind this call); `dbias` non-null still says
+    // that the bias-gradient column sums are wanted
+    const bool defer = !dgamma && !dbeta;
+    POLUS_REQUIRE(dy && x && gamma && mean && rstd && dx && (defer || (dgamma && dbeta)), "polus_layernorm_bwd: null pointer");
     POLUS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (long)rows * H < (1LL << 32), "polus_layernorm_bwd: bad dropout arguments");
     POLUS_REQUIRE(!(drop_p > 0.f) || dx_masked, "polus_layernorm_bwd: dropout needs dx_masked");
     DropArgs drop{drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u, seed, 1.0f / (1.0f - drop_p), polus_dyn()};
@@ -757,6 +761,7 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
         POLUS_NC_DISPATCH(H, float, ln_bwd_kernel, dim3(blocks), dim3(64 * BWD_WAVES), lds, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, H, wb, (float*)dx_masked, drop);
     else POLUS_FAIL("polus_layernorm_bwd: bad dtype");
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd");
+    if (defer) return POLUS_OK;
     int ncols = (wb ? 3 : 2) * H;
     if (blocks > polus_cfg().ln_fin_single) {
         // two fixed-order stages: [blocks] -> [groups] -> result (a single stage would leave most
@@ -773,6 +778,33 @@ extern "C" int polus_layernorm_bwd(int dtype, const void* dy, const void* x, con
                            partial, blocks, 3 * H, ncols, H, dgamma, dbeta, dbias, accumulate, 0);
     }
     POLUS_CHECK_LAUNCH("polus_layernorm_bwd(finalize)");
+    return POLUS_OK;
+}
+
+// Second half of polus_layernorm_bwd when it was called with dgamma = dbeta = null: the fixed-order reduction of the
+// [workgroups][3H] partials left in `workspace` into dgamma / dbeta (/ dbias).  Same kernels, same order, same result.
+extern "C" int polus_layernorm_bwd_finalize(void* workspace, size_t workspace_bytes, int rows, int H, float* dgamma, float* dbeta,
+                                            float* dbias, int accumulate, void* stream) {
+    POLUS_REQUIRE(workspace && dgamma && dbeta && rows > 0 && H > 0 && H % 4 == 0, "polus_layernorm_bwd_finalize: bad arguments");
+    size_t need = polus_layernorm_bwd_workspace_bytes(rows, H);
+    if (workspace_bytes < need) { polus_set_error("polus_layernorm_bwd_finalize: workspace %zu < %zu", workspace_bytes, need); return POLUS_ERR_WORKSPACE; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int blocks = ln_bwd_blocks(rows);
+    float* partial = static_cast<float*>(workspace);
+    const int ncols = (dbias ? 3 : 2) * H;
+    if (blocks > polus_cfg().ln_fin_single) {
+        int groups = (blocks + FIN_GROUP - 1) / FIN_GROUP;
+        float* part2 = partial + (size_t)blocks * 3 * H;
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64, groups), dim3(1024), 0, st,
+                           partial, blocks, 3 * H, ncols, ncols, part2, (float*)nullptr, (float*)nullptr, 0, FIN_GROUP);
+        POLUS_CHECK_LAUNCH("polus_layernorm_bwd_finalize(1)");
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, st,
+                           part2, groups, ncols, ncols, H, dgamma, dbeta, dbias, accumulate, 0);
+    } else {
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, st,
+                           partial, blocks, 3 * H, ncols, H, dgamma, dbeta, dbias, accumulate, 0);
+    }
+    POLUS_CHECK_LAUNCH("polus_layernorm_bwd_finalize");
     return POLUS_OK;
 }
 

@@ -220,16 +220,23 @@ class BertLayer:
         dx = scratch("dx%d" % (self.index & 1), (T, H))
         # z2 = dropout(ffn2(f)) + a1: the residual path takes dz2, the Dense path dz2 * mask/(1-p)
         dz2m = scratch("dz2m" + par, (T, H)) if p_hid > 0 else None
+        # With the side stream, the two small reductions that finish dgamma / dbeta / the Dense bias gradients of the layer's
+        # LayerNorms leave the critical path: the main kernels keep their per-workgroup partial sums (buffers by layer
+        # parity, like the dY tensors) and the finalisations are queued behind the weight-gradient launch on `side`.
+        lnp = None
+        if side is not None and os.environ.get("POLUS_LN_DEFER_FINALIZE", "1") != "0":
+            nfl = ops.layernorm_bwd_partial_floats(T, H)
+            lnp = [scratch("lnp2" + par, (nfl,), torch.float32), scratch("lnp1" + par, (nfl,), torch.float32)]
         ops.layernorm_bwd(dy, bb["z2"], self.ln2_g.value, bb["m2"], bb["r2"], dz2,
                           self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate,
-                          dx_masked=dz2m, drop_p=p_hid, seed=seeds[2])
+                          dx_masked=dz2m, drop_p=p_hid, seed=seeds[2], partials=lnp[0] if lnp else None)
         dz2d = dz2m if dz2m is not None else dz2
         gemm_dx(dz2d, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
         gemm_dx(du, self.ffn1_w, da1, resid=dz2)
         dz1m = scratch("dz1m" + par, (T, H)) if p_hid > 0 else None
         ops.layernorm_bwd(da1, bb["z1"], self.ln1_g.value, bb["m1"], bb["r1"], dz1,
                           self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate,
-                          dx_masked=dz1m, drop_p=p_hid, seed=seeds[1])
+                          dx_masked=dz1m, drop_p=p_hid, seed=seeds[1], partials=lnp[1] if lnp else None)
         dz1d = dz1m if dz1m is not None else dz1
         gemm_dx(dz1d, self.out_w, dctx)
         ops.attention_bwd(bb["qkv"], mask, bb["ctx"], dctx, bb["lse"], dqkv, B, S, A, drop_p=p_att, seed=seeds[0])
@@ -246,6 +253,9 @@ class BertLayer:
             side.wait_event(self._ev[0])
             with _lib.stream_scope(side):
                 dense_bwd_params_group(problems, accumulate)
+                if lnp:
+                    ops.layernorm_bwd_finalize(lnp[0], T, H, self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate)
+                    ops.layernorm_bwd_finalize(lnp[1], T, H, self.ln1_g.grad, self.ln1_b.grad, self.out_b.grad, accumulate)
                 self._ev[1].record(side)
             self.dw_done = self._ev[1]
         gemm_dx(dqkv, self.qkv_w, dx, resid=dz1)
@@ -465,10 +475,11 @@ class BertModel(SavableModel):
         self.overlap_dw = os.environ.get("POLUS_OVERLAP_DW", "1") != "0"
         self._side = None
 
-    def scratch(self, key, shape):
+    def scratch(self, key, shape, dtype=None):
+        dtype = dtype or self.compute_dtype
         t = self._scratch.get(key)
-        if t is None or t.shape != tuple(shape) or t.dtype != self.compute_dtype:
-            t = self._scratch[key] = torch.empty(tuple(shape), dtype=self.compute_dtype, device=self.arena.device)
+        if t is None or t.shape != tuple(shape) or t.dtype != dtype:
+            t = self._scratch[key] = torch.empty(tuple(shape), dtype=dtype, device=self.arena.device)
         return t
 
     def load_numpy_params(self, params, head_w=None, head_b=None):

@@ -177,17 +177,38 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
                                   rows, H, float(eps), _st()), "polus_layernorm_fwd")
 
 
+def layernorm_bwd_partial_floats(rows, H):
+    """f32 elements of a partial-sum buffer for layernorm_bwd(..., partials=...)."""
+    return (_lib.load().polus_layernorm_bwd_workspace_bytes(rows, H) + 3) // 4
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias=None, accumulate=False, dx_masked=None,
-                  drop_p=0.0, seed=0):
+                  drop_p=0.0, seed=0, partials=None):
+    """`partials` (f32 tensor of layernorm_bwd_partial_floats elements, owned by the caller): stop after the main kernel and
+    leave the per-workgroup sums there; dgamma / dbeta / dbias are then written by layernorm_bwd_finalize, which the caller
+    queues on any stream ordered behind this call."""
     lib = _lib.load()
     _req_cuda(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dbias)
     rows, H = x.shape
     assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous()
     nb = lib.polus_layernorm_bwd_workspace_bytes(rows, H)
+    if partials is not None:
+        assert partials.dtype == torch.float32 and partials.numel() * 4 >= nb and partials.is_contiguous()
+        check(lib.polus_layernorm_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                      None, None, ptr(dbias), int(accumulate), rows, H,
+                                      ptr(dx_masked), float(drop_p), int(seed) & 0xFFFFFFFF, ptr(partials), partials.numel() * 4, _st()),
+              "polus_layernorm_bwd")
+        return
     ws = workspace(x.device).get(nb)
     check(lib.polus_layernorm_bwd(dtype_code(x.dtype), ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
                                   ptr(dgamma), ptr(dbeta), ptr(dbias), int(accumulate), rows, H,
                                   ptr(dx_masked), float(drop_p), int(seed) & 0xFFFFFFFF, ptr(ws), nb, _st()), "polus_layernorm_bwd")
+
+
+def layernorm_bwd_finalize(partials, rows, H, dgamma, dbeta, dbias=None, accumulate=False):
+    _req_cuda(partials, dgamma, dbeta, dbias)
+    check(_lib.load().polus_layernorm_bwd_finalize(ptr(partials), partials.numel() * 4, rows, H, ptr(dgamma), ptr(dbeta), ptr(dbias),
+                                                   int(accumulate), _st()), "polus_layernorm_bwd_finalize")
 
 
 def embed_ln_fwd(ids, type_ids, word, pos, typ, gamma, beta, y, mean, rstd, eps, drop_p=0.0, seed=0):
