@@ -178,7 +178,9 @@ class BertLayer:
             t = self._bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=dev)
         return t
 
-    def forward(self, x, mask, B, S, p_hid=0.0, p_att=0.0, seeds=(0, 0, 0)):
+    def forward(self, x, mask, B, S, p_hid=0.0, p_att=0.0, seeds=(0, 0, 0), for_backward=True):
+        """`for_backward=False` (inference, the frozen encoders of the dual-encoder trainer): the GELU pre-activation is
+        not written -- half of FFN1's output bytes, a launch that is bound by exactly those."""
         cfg = self.cfg
         H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         T, dt, dev = B * S, x.dtype, x.device
@@ -186,7 +188,7 @@ class BertLayer:
         qkv, ctx, lse = b("qkv", (T, 3 * H)), b("ctx", (T, H)), b("lse", (B, A, S), torch.float32)
         z1, a1 = b("z1", (T, H)), b("a1", (T, H))
         m1, r1 = b("m1", (T,), torch.float32), b("r1", (T,), torch.float32)
-        u, f = b("u", (T, I)), b("f", (T, I))
+        u, f = (b("u", (T, I)) if for_backward else None), b("f", (T, I))
         z2, y = b("z2", (T, H)), b("y", (T, H))
         m2, r2 = b("m2", (T,), torch.float32), b("r2", (T,), torch.float32)
         ops.gemm(x, self.qkv_w.compute, qkv, bias=self.qkv_b.value, split_k="auto")
@@ -196,7 +198,7 @@ class BertLayer:
         ops.gemm(a1, self.ffn1_w.compute, f, bias=self.ffn1_b.value, aux=u, act="gelu", flags=ops.GEMM_ACT_FWD, split_k="auto")
         ops.gemm(f, self.ffn2_w.compute, z2, bias=self.ffn2_b.value, resid=a1, drop_p=p_hid, seed=seeds[2], split_k="auto")
         ops.layernorm_fwd(z2, self.ln2_g.value, self.ln2_b.value, y, m2, r2, cfg.layer_norm_eps)
-        self._stash = (x, mask, B, S, p_hid, p_att, seeds)
+        self._stash = (x, mask, B, S, p_hid, p_att, seeds) if for_backward else None
         return y
 
     def backward(self, dy, scratch, accumulate=False, side=None):
@@ -210,6 +212,8 @@ class BertLayer:
         layers later)."""
         cfg = self.cfg
         H, I, A = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+        if self._stash is None:
+            raise RuntimeError("BertLayer.backward: the last forward pass ran with training=False (nothing was kept for backward)")
         x, mask, B, S, p_hid, p_att, seeds = self._stash
         T = B * S
         bb = self._bufs
@@ -510,7 +514,7 @@ class BertModel(SavableModel):
         p_att = cfg.attention_probs_dropout_prob if training else 0.0
         for l in self.layer:
             seeds = tuple(self.site_seed(l.index, k) for k in range(3))
-            hidden = l.forward(hidden, attention_mask, B, S, p_hid, p_att, seeds)
+            hidden = l.forward(hidden, attention_mask, B, S, p_hid, p_att, seeds, for_backward=training)
         return hidden
 
     def call(self, input_ids=None, attention_mask=None, token_type_ids=None, training=False, hidden_states=None, **kw):
@@ -654,7 +658,7 @@ class TFBertSplited(PolusModel):
         p_hid = self.config.hidden_dropout_prob if train else 0.0
         p_att = self.config.attention_probs_dropout_prob if train else 0.0
         for l in self.layer:
-            hidden = l.forward(hidden, mask, B, S, p_hid, p_att, tuple(self.site_seed(l.index, k) for k in range(3)))
+            hidden = l.forward(hidden, mask, B, S, p_hid, p_att, tuple(self.site_seed(l.index, k) for k in range(3)), for_backward=bool(training))
         if train:
             self.dropout_step += 1
         self._shape = (B, S)
