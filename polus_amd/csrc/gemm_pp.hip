@@ -478,7 +478,7 @@ int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStrea
         // the GELU ones of BERT-base (FFN1 forward, dU: -8 % from cold caches) and every multi-round launch of BERT-large (+0.5 %
         // on the c4 step) -- and is neutral to slightly negative on the 192-wide bias-only QKV launch of BERT-base (three exact
         // rounds, an epilogue too short to hide anything); POLUS_GEMM_PERSIST=2 forces it everywhere
-        const bool wins = tn == 256 || a.persist_all;
+        const bool wins = tn == 256 || a.persist_all;     // 192-wide launches lose with it (c5, 512 tiles of 256 x 192: 34.4 -> 34.8 ms/step)
         if (tiles > a.persist && wins) {
             if (tn == 256) return launch_ppp_mode<4>(a, mode, drop, a.persist, st);
             if (tn == 192) return launch_ppp_mode<3>(a, mode, drop, a.persist, st);

@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python3 -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "persistent or pingpong" 2>&1 | tail -2
+for pv in 0 1 0 1; do POLUS_GEMM_PERSIST=$pv python3 bench.py --config c5 --steps 10 --warmup 3 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read());print('c5 persist=$pv', d['value'], d['ms_per_step'])"; done
