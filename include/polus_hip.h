@@ -53,6 +53,10 @@ int polus_device_info(int* n_cu, int* lds_bytes_per_cu, char* arch, int arch_len
 /* The POLUS_* tuning switches of the library are read from the environment once, at the first call
  * that needs one; this re-reads them (A/B tools and tests that flip a switch inside one process). */
 int polus_reload_env(void);
+/* POLUS_GEMM_RESERVE_CUS (CUs the GEMM tile-shape choice and the persistent grids leave to concurrent RCCL channel
+ * kernels) applies only while this is on (default on).  The data-parallel trainer switches it on for backward, where the
+ * bucketed exchange runs beside the GEMMs, and off for the forward pass. */
+int polus_set_reserve_active(int on);
 /* Per-step scalars from device memory, for steps replayed from a captured HIP graph (the kernel arguments of a
  * replay are frozen).  `dev_block16` points to 16 bytes in HBM, {uint32 salt; float lr; float lr_t; uint32 0},
  * that the caller rewrites before each replay; NULL unregisters.  While a block is registered

@@ -23,6 +23,7 @@ SIGNATURES = {
     "polus_abi_version": (_i, []),
     "polus_device_info": (_i, [_c.POINTER(_i), _c.POINTER(_i), _c.c_char_p, _i]),
     "polus_reload_env": (_i, []),
+    "polus_set_reserve_active": (_i, [_i]),
     "polus_set_dynamic_params": (_i, [_vp]),
     "polus_gemm_workspace_bytes": (_sz, [_i, _i, _i]),
     "polus_gemm_auto_split": (_i, [_i, _i, _i]),

@@ -254,7 +254,8 @@ def init():
         # takes no tile: cap the channels (POLUS_RCCL_MAX_CHANNELS, default 16; an explicit NCCL_MAX_NCHANNELS wins) and let
         # the GEMM tile-shape choice plan for that many CUs fewer (POLUS_GEMM_RESERVE_CUS; csrc/gemm.hip pp_tile), so that a
         # 256-tile launch does not find 240 CUs and run two rounds.  The exchange has ~8 ms of backward to hide under and
-        # needs ~60 GB/s per direction and link for that: 16 channels are ample.
+        # needs ~60 GB/s per direction and link for that: 16 channels are ample.  The reserve is switched on only around
+        # backward (training.py _train_step): the forward pass runs beside no collective and keeps all 256 CUs.
         cap = os.environ.get("POLUS_RCCL_MAX_CHANNELS", "16")
         os.environ.setdefault("NCCL_MAX_NCHANNELS", cap)
         if "POLUS_GEMM_RESERVE_CUS" not in os.environ:
@@ -262,6 +263,7 @@ def init():
             try:
                 from . import _lib
                 _lib.check(_lib.load().polus_reload_env(), "polus_reload_env")
+                _lib.check(_lib.load().polus_set_reserve_active(0), "polus_set_reserve_active")
             except Exception:       # noqa: BLE001 -- the library is loaded (and reads its switches) later in that case
                 pass
     if not dist.is_initialized():

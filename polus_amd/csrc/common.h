@@ -52,6 +52,7 @@ struct PolusCfg {
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward (bf16): 64-key blocks by LDS-DMA at S = 256, 32-key blocks at S = 64 / 128, key-resident from S = 512; 2 / 3 force the 64- / 32-key-block kernel; 0 = two kernels
 };
 const PolusCfg& polus_cfg();
+int polus_reserved_cus();   // cfg.reserve_cus while the reserve is switched on (polus_set_reserve_active), else 0
 
 // ---------------------------------------------------------------- per-step scalars in device memory
 // A captured HIP graph replays the SAME kernel arguments every step, so what changes from step to step --

@@ -321,7 +321,7 @@ static int pp_tile(int M, int N, int K, int mode, bool vec16) {
     // CUs a launch can count on: all of them, minus what a concurrent gradient exchange holds (POLUS_GEMM_RESERVE_CUS: a
     // ping-pong workgroup fills a CU's registers and LDS, so a CU running an RCCL channel kernel takes no tile, and a
     // 256-tile launch that finds 240 free CUs runs two rounds)
-    const int ncu = max(32, polus_num_cus() - polus_cfg().reserve_cus);
+    const int ncu = max(32, polus_num_cus() - polus_reserved_cus());
     const long tm = (M + 255) / 256;
     double best = 0.0; int best_tn = 0;
     for (int tn : {256, 192}) {
@@ -460,7 +460,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
     a.ablate = polus_cfg().ablate;
     a.order = polus_cfg().gemm_order;
-    a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_cfg().reserve_cus) : 0;
+    a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
@@ -611,7 +611,7 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     a.colsum_a = cs_ws;
     a.ablate = polus_cfg().ablate;
     a.order = polus_cfg().gemm_order;
-    a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_cfg().reserve_cus) : 0;
+    a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
     int rc;
     if (splits_eff > 1) {

@@ -47,6 +47,12 @@ const PolusCfg& polus_cfg() {
 }
 extern "C" int polus_reload_env(void) { read_cfg(); return POLUS_OK; }
 
+// The CU reserve only pays while a collective's channel kernels are resident: the trainer switches it on around backward
+// (where the bucketed exchange runs) and off for the forward pass, which shares the chip with nothing.
+static int g_reserve_on = 1;
+extern "C" int polus_set_reserve_active(int on) { g_reserve_on = on != 0; return POLUS_OK; }
+int polus_reserved_cus() { return g_reserve_on ? polus_cfg().reserve_cus : 0; }
+
 static const PolusDyn* g_dyn = nullptr;
 const PolusDyn* polus_dyn() { return g_dyn; }
 extern "C" int polus_set_dynamic_params(const void* dev_block16) {

@@ -79,6 +79,12 @@ def set_env(name, value=None):
     _AUTO_SPLIT.clear()
 
 
+def reserve_cus(active):
+    """Switch the CU reserve of the GEMM launches (POLUS_GEMM_RESERVE_CUS) on or off: on while RCCL's channel kernels
+    share the chip (backward of a data-parallel step), off otherwise (include/polus_hip.h polus_set_reserve_active)."""
+    check(_lib.load().polus_set_reserve_active(1 if active else 0), "polus_set_reserve_active")
+
+
 def _req_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:

@@ -284,7 +284,15 @@ class BaseTrainer:
             self.optimizer.grad_scale = 1.0 / accum
             updater.begin()
             self.model.grad_ready_hook = updater.on_ready
-        self.backward_from_loss(accumulate=not first)
+        if reducers:
+            # the bucketed exchange runs beside the GEMMs from here on: leave RCCL's channel kernels their CUs
+            from . import ops
+            ops.reserve_cus(True)
+        try:
+            self.backward_from_loss(accumulate=not first)
+        finally:
+            if reducers:
+                ops.reserve_cus(False)
         self.step_counter_micro = micro + 1
         self._exposed_mark(0)
         if updater is not None:

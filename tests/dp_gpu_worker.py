@@ -67,6 +67,10 @@ def main():
         calls.append((n, kw))
         return orig(gv, **kw)
     opt.apply_gradients = counted
+    # the CU reserve for RCCL's channel kernels is on exactly around a backward pass that carries the exchange
+    from polus_amd import ops
+    toggles, orig_reserve = [], ops.reserve_cus
+    ops.reserve_cus = lambda on: (toggles.append(bool(on)), orig_reserve(on))[1]
     callbacks = []
     if validate:
         # polus/callbacks.py:218-261 under data parallelism: every rank predicts its own validation shard on the GPU,
@@ -95,6 +99,7 @@ def main():
             assert both[0] != both[1], "the two validation shards should differ"
     assert trainer._dp_mode() == scheme
     steps *= epochs
+    assert toggles == [True, False] * steps, toggles
     if scheme == "allreduce":
         # the update of every bucket is queued behind its all-reduce: one launch per bucket and step, every
         # variable exactly once per step, the step counter advanced by the first launch only
