@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --gpus N ...          # bare: the parent spawns the N ranks itself (before it touches torch or the GPU)
-    python bench.py --config c2|c4|c5     # the other BASELINE.json workloads, same JSON schema (default c3 = the headline)
+    python bench.py --config c2|c4|c5|c5m16  # the other BASELINE.json workloads, same JSON schema (default c3 = the headline)
 
 A step = one full ClassifierTrainer.train_step (forward, loss, backward, bucketed RCCL
 gradient all-reduce when N > 1, fused AdamW) on one synthetic batch already resident in HBM.
@@ -42,8 +42,12 @@ N_LABELS = 4                                      # PAD, O, B-Chemical, I-Chemic
 WORKLOADS = {
     "c3": dict(label="BASELINE.json configs[2] per-GPU shape", large=False, batch=64, seq=256, accum=1, kind="ner"),
     "c2": dict(label="BASELINE.json configs[1]", large=False, batch=32, seq=128, accum=1, kind="ner"),
-    "c5": dict(label="BASELINE.json configs[4] per-GPU shape: 64 samples as 4 micro-steps of 16, one exchange + AdamW per step",
-               large=False, batch=64, seq=512, accum=4, kind="ner"),
+    # configs[4] names no batch size: c5 keeps configs[2]'s 64 samples/GPU per micro-step (256 per optimizer step),
+    # c5m16 is the small-micro-batch reading (16 per micro-step, 64 per optimizer step) rounds 1-2 quoted
+    "c5": dict(label="BASELINE.json configs[4] per-GPU shape: seq 512, 4 micro-steps of 64 samples (configs[2]'s per-GPU batch), "
+                     "one exchange + AdamW per 256 samples", large=False, batch=256, seq=512, accum=4, kind="ner"),
+    "c5m16": dict(label="BASELINE.json configs[4] read with 16-sample micro-steps: 64 samples as 4 micro-steps of 16, one "
+                        "exchange + AdamW per step", large=False, batch=64, seq=512, accum=4, kind="ner"),
     "c4": dict(label="BASELINE.json configs[3] per-GPU shape: dual encoder, both BERT-large encoders frozen (forward only, "
                      "polus/ir/training.py:69-75), projections + in-batch softmax CE trained",
                large=True, batch=64, seq=512, accum=1, kind="ir"),
@@ -432,6 +436,7 @@ def main():
     if rank == 0:
         metric = {"c3": "train samples/sec BioBERT-base NER seq256", "c2": "train samples/sec BioBERT-base NER seq128 bs32",
                   "c5": "train samples/sec BioBERT-base NER seq512 grad-accum x4",
+                  "c5m16": "train samples/sec BioBERT-base NER seq512 grad-accum x4 (micro-batch 16)",
                   "c4": "train query-document pairs/sec PubMedBERT-large dual encoder seq512"}[args.config]
         what = (f"dual encoder (two frozen encoder passes + projections E=128 + in-batch softmax CE, Adam 1e-3), seq_len={S}, {B} pairs/GPU"
                 if args.kind == "ir" else

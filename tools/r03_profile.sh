@@ -24,11 +24,11 @@ python3 tools/kstats.py $O/stats_ov/*/*kernel_stats.csv 8 > $O/step_kernel_stats
 python3 tools/hbm_traffic.py $O/pmc_fetch $O/pmc_write $O/gemm_hbm_traffic.json
 python3 tools/hbm_traffic.py $O/pmc_fetch_o0 $O/pmc_write $O/gemm_hbm_traffic_order0.json
 for f in $O/pmc_attn/*/*counter_collection.csv; do python3 tools/pmc_summary.py $f attn > $O/attention_pmc.txt; done
-for c in c2 c5 c4; do
+for c in c2 c5 c5m16 c4; do
   python3 bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err || exit 1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$c -- python3 bench.py --config $c --steps 5 --warmup 2 > $O/stats_$c.log 2>&1 || exit 1
   python3 tools/kstats.py $O/stats_$c/*/*kernel_stats.csv 8 > $O/${c}_kernel_stats_summary.txt
 done
 cp $O/stats/*/*kernel_stats.csv $O/step_kernel_stats.csv
-rm -rf $O/stats $O/stats_ov $O/pmc_fetch $O/pmc_write $O/pmc_fetch_o0 $O/pmc_mfma $O/pmc_attn $O/stats_c2 $O/stats_c4 $O/stats_c5
+rm -rf $O/stats $O/stats_ov $O/pmc_fetch $O/pmc_write $O/pmc_fetch_o0 $O/pmc_mfma $O/pmc_attn $O/stats_c2 $O/stats_c4 $O/stats_c5 $O/stats_c5m16
 cat $O/bench_line.json; cat $O/step_kernel_stats_summary.txt
