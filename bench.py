@@ -42,8 +42,9 @@ N_LABELS = 4                                      # PAD, O, B-Chemical, I-Chemic
 WORKLOADS = {
     "c3": dict(label="BASELINE.json configs[2] per-GPU shape", large=False, batch=64, seq=256, accum=1, kind="ner"),
     "c2": dict(label="BASELINE.json configs[1]", large=False, batch=32, seq=128, accum=1, kind="ner"),
-    # configs[4] names no batch size: c5 keeps configs[2]'s 64 samples/GPU per micro-step (256 per optimizer step),
-    # c5m16 is the small-micro-batch reading (16 per micro-step, 64 per optimizer step) rounds 1-2 quoted
+    # configs[4] names no batch size and SURVEY.md section 8 reads it both ways: row a8 has T = 32768 tokens per GPU and
+    # micro-step (64 x 512, configs[2]'s per-GPU batch) = c5; the FLOP table of 8(d) assumes 64 samples as 4 x 16 = c5m16
+    # (what rounds 1-2 quoted as c5)
     "c5": dict(label="BASELINE.json configs[4] per-GPU shape: seq 512, 4 micro-steps of 64 samples (configs[2]'s per-GPU batch), "
                      "one exchange + AdamW per 256 samples", large=False, batch=256, seq=512, accum=4, kind="ner"),
     "c5m16": dict(label="BASELINE.json configs[4] read with 16-sample micro-steps: 64 samples as 4 micro-steps of 16, one "
