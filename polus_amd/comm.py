@@ -251,12 +251,13 @@ def init():
     if use_gpu and backend != "gloo":
         # RCCL's channel kernels are persistent workgroups, one CU each, for as long as a collective runs.  The GEMMs of the
         # step keep ONE 512-thread, 128 KiB workgroup per CU (all of a CU's registers and LDS), so a CU that runs a channel
-        # takes no tile: cap the channels (POLUS_RCCL_MAX_CHANNELS, default 16; an explicit NCCL_MAX_NCHANNELS wins) and let
+        # takes no tile: cap the channels (POLUS_RCCL_MAX_CHANNELS, default 32; an explicit NCCL_MAX_NCHANNELS wins) and let
         # the GEMM tile-shape choice plan for that many CUs fewer (POLUS_GEMM_RESERVE_CUS; csrc/gemm.hip pp_tile), so that a
         # 256-tile launch does not find 240 CUs and run two rounds.  The exchange has ~8 ms of backward to hide under and
-        # needs ~60 GB/s per direction and link for that: 16 channels are ample.  The reserve is switched on only around
+        # needs ~60 GB/s per direction and link for that.  32 rather than 16: every launch of the step has the same number of
+        # tile rounds on 224 CUs as on 240 (192-, 216-, 576- and 768-tile launches), so the headroom for the exchange is free.  The reserve is switched on only around
         # backward (training.py _train_step): the forward pass runs beside no collective and keeps all 256 CUs.
-        cap = os.environ.get("POLUS_RCCL_MAX_CHANNELS", "16")
+        cap = os.environ.get("POLUS_RCCL_MAX_CHANNELS", "32")
         os.environ.setdefault("NCCL_MAX_NCHANNELS", cap)
         if "POLUS_GEMM_RESERVE_CUS" not in os.environ:
             os.environ["POLUS_GEMM_RESERVE_CUS"] = os.environ["NCCL_MAX_NCHANNELS"]
