@@ -43,6 +43,7 @@ struct PolusCfg {
     int gemm_ring128;      // POLUS_GEMM_RING128: -1 never, 0 (default) where the heuristic picks it, 1 wherever it applies (bf16 C, K-contiguous operands)
     int gemm_auto_split;   // POLUS_GEMM_AUTO_SPLIT: 1 (default) polus_gemm_auto_split recommends K slices for under-filled bf16 Dense GEMMs; 0 = always 1
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
+    int gemm_stagger_us;   // POLUS_GEMM_STAGGER_US: start delay of every other workgroup of the persistent ping-pong GEMM (default 6, 0 = none)
     int gemm_order;        // POLUS_GEMM_ORDER: column tiles an XCD's concurrent ping-pong tiles span (0 = row-major run; default 4)
     int gemm_persist;      // POLUS_GEMM_PERSIST: 1 (default) = the multi-round 256-wide launches as one persistent workgroup per CU (next tile's prologue under the epilogue), 2 = every multi-round ping-pong launch, 0 = never
     int reserve_cus;       // POLUS_GEMM_RESERVE_CUS: CUs the tile-shape choice leaves to concurrent RCCL channel kernels (default 0)

@@ -460,6 +460,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
     a.ablate = polus_cfg().ablate;
     a.order = polus_cfg().gemm_order;
+    a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -611,6 +612,7 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     a.colsum_a = cs_ws;
     a.ablate = polus_cfg().ablate;
     a.order = polus_cfg().gemm_order;
+    a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
     int rc;

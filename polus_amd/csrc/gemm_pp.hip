@@ -302,6 +302,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
     int m0 = trow * TM, n0 = tcol * TN;
     set_tile(m0, n0);
     issue_prologue();
+    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        // Every other workgroup of an XCD starts p.stagger x 10 ns late (its first operands are already in flight).  All CUs
+        // walk equal tiles in step, so their epilogues -- 64 MB of HBM traffic per round of tiles on the GELU launches -- would
+        // all fall into the same few microseconds, in which no matrix instruction issues anywhere; half a phase apart, each
+        // half's burst passes under the other half's K loop.  The idle start is paid once, the bursts come once per tile:
+        // 6 us is worth -0.25 ... -0.47 % on the step on three boxes (interleaved A/B, tools/exp/stagger_ab.sh,
+        // profiles/r03_ab_stagger.txt); alone and from cold caches the dU launch gains 2 us and FFN1 forward moves by
+        // -0.5 ... +3 us depending on the box.
+        const unsigned long t0 = wall_clock64(), dt = (unsigned long)p.stagger;
+        while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+    }
 
     for (; it < ntiles; it += gridDim.x) {
         f32x4 acc[8][NT];

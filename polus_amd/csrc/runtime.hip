@@ -26,6 +26,7 @@ static void read_cfg() {
     g_cfg.dw_ungrouped = getenv("POLUS_DW_UNGROUPED") != nullptr;
     g_cfg.ablate = env_int("POLUS_GEMM_ABLATE", 0);
     g_cfg.gemm_order = env_int("POLUS_GEMM_ORDER", 4);
+    g_cfg.gemm_stagger_us = env_int("POLUS_GEMM_STAGGER_US", 6);
     g_cfg.reserve_cus = env_int("POLUS_GEMM_RESERVE_CUS", 0);
     g_cfg.gemm_persist = env_int("POLUS_GEMM_PERSIST", 1);
     g_cfg.attn_waves = env_int("POLUS_ATTN_WAVES", 0);
