@@ -243,6 +243,16 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
     batches = device_batches(args, rank, model.arena.device)
     one_step = make_step(args, trainer, batches)
 
+    # N > 1: let the trainer measure, on this node, whether the GEMMs of an exchanging backward pass should leave CUs to
+    # RCCL's channel kernels (untimed real training steps before the warm-up; every rank takes part)
+    tuned = None
+    if world > 1 and os.environ.get("POLUS_DP_TUNE", "1") != "0":
+        tick = [0]
+
+        def tune_step():
+            tick[0] += 1
+            return one_step(10_000 + tick[0])
+        tuned = trainer.tune_data_parallel(tune_step, steps=4)
     first_loss = None
     for k in range(warmup):
         l = one_step(k)
@@ -315,6 +325,8 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
            "loss_first": round(first_loss, 5) if first_loss is not None else None, "loss_last": round(last_loss, 5)}
     if roof:
         out["roofline"] = roof
+    if tuned is not None:
+        out["dp_tuning"] = tuned
     if world > 1:
         # what the exchange costs: (a) the tail behind backward that nothing overlapped (HIP events, mean over the timed
         # steps, max over ranks); (b) the same steps with every rank training alone -- no exchange at all (the replicas
@@ -460,6 +472,7 @@ def main():
         if world > 1:
             out.update(rccl_ranks=plane["ranks_seen"], data_plane=plane["data_plane"],
                        exposed_comm_ms=head.get("exposed_comm_ms"), ms_per_step_nocomm=head.get("ms_per_step_nocomm"),
+                       dp_tuning=head.get("dp_tuning"),
                        multi_gpu_parity="unpinned: no multi-GPU box in the build environment; two-rank equivalence is tested "
                                         "over gloo (tests/test_distributed_cpu.py, tests/test_dp_gpu.py)")
             if "rccl_comm_count" in plane:

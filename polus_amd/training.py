@@ -284,14 +284,15 @@ class BaseTrainer:
             self.optimizer.grad_scale = 1.0 / accum
             updater.begin()
             self.model.grad_ready_hook = updater.on_ready
-        if reducers:
+        reserve = bool(reducers) and getattr(self, "reserve_cus_in_backward", True)
+        if reserve:
             # the bucketed exchange runs beside the GEMMs from here on: leave RCCL's channel kernels their CUs
             from . import ops
             ops.reserve_cus(True)
         try:
             self.backward_from_loss(accumulate=not first)
         finally:
-            if reducers:
+            if reserve:
                 ops.reserve_cus(False)
         self.step_counter_micro = micro + 1
         self._exposed_mark(0)
@@ -364,6 +365,33 @@ class BaseTrainer:
             self.optimizer.apply_gradients(zip(grads, self.trainable_weights))
         self._exposed_mark(1)
         return loss_value
+
+    def tune_data_parallel(self, one_step, steps=4):
+        """Measured choice of the one data-parallel switch whose best setting depends on how RCCL's channel kernels and the
+        GEMMs share the CUs of the machine at hand: whether the GEMM launches of an exchanging backward pass leave CUs to the
+        channels (`reserve_cus_in_backward`, comm.init / DESIGN.md section 5).  `one_step()` runs one optimizer step (all its
+        micro-steps) on this rank's next batch; every rank calls this at the same point.  2 x (1 + steps) real training
+        steps are taken; the setting whose slowest rank was faster is kept on every rank (the times are maxima over the
+        ranks, hence identical everywhere).  Results do not depend on the setting (same arithmetic, other tile shapes).
+        Returns {"reserve_on_ms", "reserve_off_ms", "reserve_cus_in_backward"} or None when there is nothing to choose."""
+        import time
+        import torch
+        if not self.use_horovod or hvd.size() == 1 or not torch.cuda.is_available():
+            return None
+        per = {}
+        for setting in (True, False):
+            self.reserve_cus_in_backward = setting
+            one_step()
+            torch.cuda.synchronize()
+            comm.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_step()
+            torch.cuda.synchronize()
+            per[setting] = comm.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+        self.reserve_cus_in_backward = per[True] <= per[False]
+        return {"reserve_on_ms": round(per[True], 3), "reserve_off_ms": round(per[False], 3),
+                "reserve_cus_in_backward": self.reserve_cus_in_backward}
 
     def _exposed_mark(self, which):
         """`trainer.measure_exposed = True` (bench.py, data-parallel runs): HIP events on the compute stream right behind

@@ -140,3 +140,7 @@ def test_bench_bare_multi_gpu_launch_line(tmp_path):
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["exposed_comm_ms"] > 0 and out["ms_per_step_nocomm"] > 0 and out["ms_per_step"] > 0
     assert out["value"] > 0 and out["roofline"]["launches"] > 0 and "unpinned" in out["multi_gpu_parity"]
+    # the measured choice of the CU reserve ran on both ranks and both report the same decision (max-over-ranks times)
+    t = out["dp_tuning"]
+    assert t["reserve_on_ms"] > 0 and t["reserve_off_ms"] > 0
+    assert t["reserve_cus_in_backward"] == (t["reserve_on_ms"] <= t["reserve_off_ms"])
