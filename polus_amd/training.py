@@ -225,7 +225,7 @@ class BaseTrainer:
         r = self._reducers.get(id(arena))
         if r is None:
             import torch
-            bucket = int(float(os.environ.get("POLUS_BUCKET_MB", "64")) * (1 << 20))
+            bucket = int(float(getattr(self, "bucket_mb", None) or os.environ.get("POLUS_BUCKET_MB", "64")) * (1 << 20))
             mode = self._dp_mode()
             bf16 = os.environ.get("POLUS_DP_BF16", "0") == "1" and arena.grads.is_cuda
             r = comm.GradBucketReducer(arena.grads, bucket_bytes=bucket, boundaries=[v.offset for v in arena.vars],
@@ -366,21 +366,25 @@ class BaseTrainer:
         self._exposed_mark(1)
         return loss_value
 
-    def tune_data_parallel(self, one_step, steps=4):
-        """Measured choice of the one data-parallel switch whose best setting depends on how RCCL's channel kernels and the
-        GEMMs share the CUs of the machine at hand: whether the GEMM launches of an exchanging backward pass leave CUs to the
-        channels (`reserve_cus_in_backward`, comm.init / DESIGN.md section 5).  `one_step()` runs one optimizer step (all its
-        micro-steps) on this rank's next batch; every rank calls this at the same point.  2 x (1 + steps) real training
-        steps are taken; the setting whose slowest rank was faster is kept on every rank (the times are maxima over the
-        ranks, hence identical everywhere).  Results do not depend on the setting (same arithmetic, other tile shapes).
-        Returns {"reserve_on_ms", "reserve_off_ms", "reserve_cus_in_backward"} or None when there is nothing to choose."""
+    def tune_data_parallel(self, one_step, steps=4, bucket_mb=(32, 128)):
+        """Measured choice of the two data-parallel switches whose best setting depends on the node at hand -- how RCCL's
+        channel kernels and the GEMMs share its CUs, what its links deliver per message size:
+          * `reserve_cus_in_backward`: whether the GEMM launches of an exchanging backward pass leave CUs to the channels
+            (comm.init / DESIGN.md section 5);
+          * `bucket_mb`: the bucket size of the exchange, POLUS_BUCKET_MB (default 64) against the sizes given (an explicit
+            POLUS_BUCKET_MB in the environment is kept).
+        `one_step()` runs one optimizer step (all its micro-steps) on this rank's next batch; every rank calls this at the same
+        point.  (1 + steps) real training steps are taken per candidate; a candidate replaces the incumbent when its slowest
+        rank was faster (the times are maxima over the ranks, hence identical everywhere, and so is the choice).  The reserve
+        changes tile shapes only -- same results; another bucket size changes where RCCL cuts a message, hence the last
+        bits of the summed gradients, as any change of POLUS_BUCKET_MB does.
+        Returns the measured times and the choice, or None when there is nothing to choose."""
         import time
         import torch
         if not self.use_horovod or hvd.size() == 1 or not torch.cuda.is_available():
             return None
-        per = {}
-        for setting in (True, False):
-            self.reserve_cus_in_backward = setting
+
+        def measure():
             one_step()
             torch.cuda.synchronize()
             comm.barrier()
@@ -388,10 +392,30 @@ class BaseTrainer:
             for _ in range(steps):
                 one_step()
             torch.cuda.synchronize()
-            per[setting] = comm.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+            return comm.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+
+        out = {}
+        per = {}
+        for setting in (True, False):
+            self.reserve_cus_in_backward = setting
+            per[setting] = measure()
         self.reserve_cus_in_backward = per[True] <= per[False]
-        return {"reserve_on_ms": round(per[True], 3), "reserve_off_ms": round(per[False], 3),
-                "reserve_cus_in_backward": self.reserve_cus_in_backward}
+        out.update(reserve_on_ms=round(per[True], 3), reserve_off_ms=round(per[False], 3),
+                   reserve_cus_in_backward=self.reserve_cus_in_backward)
+        if "POLUS_BUCKET_MB" not in os.environ and bucket_mb:
+            best_mb, best = 64, min(per.values())
+            out["bucket_64_ms"] = round(best, 3)
+            for mb in bucket_mb:
+                self.bucket_mb = mb
+                self._reducers.clear()
+                t = measure()
+                out[f"bucket_{mb}_ms"] = round(t, 3)
+                if t < best:
+                    best_mb, best = mb, t
+            self.bucket_mb = best_mb
+            self._reducers.clear()
+            out["bucket_mb"] = best_mb
+        return out
 
     def _exposed_mark(self, which):
         """`trainer.measure_exposed = True` (bench.py, data-parallel runs): HIP events on the compute stream right behind
