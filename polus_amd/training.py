@@ -366,7 +366,7 @@ class BaseTrainer:
         self._exposed_mark(1)
         return loss_value
 
-    def tune_data_parallel(self, one_step, steps=4, bucket_mb=(32, 128)):
+    def tune_data_parallel(self, one_step, steps=4, bucket_mb=(16, 32, 128)):
         """Measured choice of the two data-parallel switches whose best setting depends on the node at hand -- how RCCL's
         channel kernels and the GEMMs share its CUs, what its links deliver per message size:
           * `reserve_cus_in_backward`: whether the GEMM launches of an exchanging backward pass leave CUs to the channels

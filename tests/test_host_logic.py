@@ -320,7 +320,7 @@ class _EchoPlane:
         return _EchoWork()
 
 
-@pytest.mark.parametrize("bucket_mb", [64, 32, 128])
+@pytest.mark.parametrize("bucket_mb", [64, 16, 32, 128])
 def test_bucket_plan_of_bert_base_at_world_8(monkeypatch, bucket_mb):
     """8-GPU readiness that needs no hardware: the bucket plans of the BERT-base gradient arena at world size 8, for the
     default bucket size and the two others trainer.tune_data_parallel tries.
