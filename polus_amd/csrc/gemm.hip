@@ -459,6 +459,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     if (aux) ev16 = ev16 && (((uintptr_t)aux) % 16 == 0) && ((ldaux * es) % 16 == 0);
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
     a.ablate = polus_cfg().ablate;
+    a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
     a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
@@ -611,6 +612,7 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     a.a_vec = a.b_vec = 1;
     a.colsum_a = cs_ws;
     a.ablate = polus_cfg().ablate;
+    a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
     a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
@@ -650,6 +652,25 @@ static bool grouped_use_pp(int n, const polus_dw_problem* pr, int T) {
     for (int k = 0; k < n; ++k)
         if (pr[k].n_out < 256 || pr[k].n_in < 256) return false;
     return true;
+}
+
+// The stream-K hybrid replaces the even split when the library chooses the slices itself (split_k <= 0), the ping-pong
+// kernel applies and the even split would leave at least 1/16 of the CUs without a workgroup.
+static bool grouped_sk_plan(int n, const polus_dw_problem* pr, int T, int split_k, PPKSSKPlan* pl) {
+    if (!polus_cfg().dw_streamk || split_k > 0 || !grouped_use_pp(n, pr, T)) return false;
+    int no[POLUS_MAX_GROUP], ni[POLUS_MAX_GROUP];
+    for (int k = 0; k < n; ++k) { no[k] = pr[k].n_out; ni[k] = pr[k].n_in; }
+    int ncu = polus_num_cus() - polus_reserved_cus();
+    if (polus_cfg().dw_sk_cus > 0 && polus_cfg().dw_sk_cus < ncu) ncu = polus_cfg().dw_sk_cus;
+    return polus_ppks_sk_plan(no, ni, n, T, ncu, polus_cfg().dw_sk_delta, pl) != 0;
+}
+static size_t grouped_sk_need(int n, const polus_dw_problem* pr, const PPKSSKPlan& pl, size_t* cs_off) {
+    size_t off = (size_t)pl.ttot * pl.slots * 256 * 256 * sizeof(float);
+    for (int k = 0; k < n; ++k) {
+        cs_off[k] = off;
+        off += (((size_t)pl.slots * pr[k].n_out * sizeof(float) + 255) / 256) * 256;
+    }
+    return off + 256;
 }
 
 static void grouped_splits(int n, const polus_dw_problem* pr, int T, int split_k, int* splits, bool pp) {
@@ -709,6 +730,12 @@ extern "C" size_t polus_dense_bwd_params_grouped_workspace_bytes(int n, const po
         size_t b = polus_dense_bwd_params_workspace_bytes(T, problems[k].n_out, problems[k].n_in, splits[k]);
         if (b > single) single = b;
     }
+    PPKSSKPlan pl;
+    if (grouped_sk_plan(n, problems, T, split_k, &pl)) {
+        size_t co2[POLUS_MAX_GROUP];
+        const size_t sk = grouped_sk_need(n, problems, pl, co2);
+        if (sk > grouped) grouped = sk;
+    }
     return grouped > single ? grouped : single;
 }
 
@@ -742,6 +769,32 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         return POLUS_OK;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    PPKSSKPlan skp;
+    if (pp && grouped_sk_plan(n, problems, T, split_k, &skp)) {
+        size_t co2[POLUS_MAX_GROUP];
+        grouped_sk_need(n, problems, skp, co2);
+        unsigned char* ws2 = static_cast<unsigned char*>(workspace);
+        GemmArgs ga2[POLUS_MAX_GROUP];
+        float* cs2[POLUS_MAX_GROUP]; float* dWs[POLUS_MAX_GROUP]; float* dbs[POLUS_MAX_GROUP];
+        long ldw[POLUS_MAX_GROUP]; int no[POLUS_MAX_GROUP], ni[POLUS_MAX_GROUP];
+        bool aligned = true;
+        for (int k = 0; k < n; ++k) {
+            const polus_dw_problem& q = problems[k];
+            GemmArgs& a = ga2[k];
+            memset(&a, 0, sizeof(a));
+            a.A = q.dY; a.B = q.X; a.lda = q.lddy; a.ldb = q.ldx;
+            a.M = q.n_out; a.N = q.n_in; a.K = T; a.alpha = 1.0f;
+            a.a_vec = a.b_vec = 1; a.epi_vec = a.epi_vec16 = 1;
+            cs2[k] = q.db ? reinterpret_cast<float*>(ws2 + co2[k]) : nullptr;
+            dWs[k] = q.dW; dbs[k] = q.db; ldw[k] = q.lddw; no[k] = q.n_out; ni[k] = q.n_in;
+            aligned = aligned && (q.n_in % 4 == 0) && (q.lddw % 4 == 0) && polus_aligned16(q.dW);
+        }
+        if (aligned) {
+            int rc2 = polus_launch_gemm_ppks_sk(ga2, skp, reinterpret_cast<float*>(ws2), cs2, st);
+            if (rc2 != POLUS_OK) return rc2;
+            return polus_launch_dw_group_reduce_sk(skp, reinterpret_cast<const float*>(ws2), cs2, dWs, dbs, ldw, no, ni, accumulate ? 1 : 0, st);
+        }
+    }
     const int bk = 64;
     const int nkt = (T + bk - 1) / bk;
     int eff[POLUS_MAX_GROUP], kps[POLUS_MAX_GROUP];

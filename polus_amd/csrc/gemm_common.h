@@ -23,6 +23,7 @@ struct GemmArgs {
     unsigned drop_thresh, drop_seed;
     float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
+    int exp;     // POLUS_EXP bits (experiments under measurement)
     int ablate;  // diagnostics only (POLUS_GEMM_ABLATE): bit0 = no in-loop DMA, bit1 = no MFMA
     int persist_all;  // POLUS_GEMM_PERSIST=2: the persistent form for every multi-round ping-pong launch (A/B)
     int persist; // gemm_pp.hip: > 0 = number of CUs for the persistent form of multi-round launches (POLUS_GEMM_PERSIST), 0 = one workgroup per tile
@@ -326,6 +327,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& p, f32x4 (&acc)[8]
 #pragma unroll
                         for (int r = 0; r < 8; ++r) tt[r] = (bf16_t)v[r];
                         // the pre-activation is only read again in the backward pass: streaming store
+                        // (round 4: plain stores here, non-temporal loads of these rows in the backward pass and non-temporal C stores
+                        // all measured within noise, profiles/r04_ab_cache_policy.txt)
                         __builtin_nontemporal_store(tt, reinterpret_cast<bf16x8_t*>(aux + m * p.ldaux + ncol));
                     }
                     apply_act_n<8, true>(p.act, v);
@@ -545,3 +548,14 @@ int polus_launch_gemm_ppks_grouped_dw(const pgemm::GemmArgs* probs, int n, const
 int polus_launch_dw_group_reduce(int n, const float* const* slabs, const float* const* cs, float* const* dW, float* const* db,
                                  const long* lddw, const int* n_out, const int* n_in, const int* splits, int accumulate,
                                  hipStream_t st);
+
+// gemm_ppks.hip: the grouped dW launch with `base` regular K-slices per tile plus a stream-K remainder on the CUs the even
+// split leaves idle.  polus_ppks_sk_plan answers 0 when the hybrid does not apply (then the even split runs).
+struct PPKSSKPlan {
+    int tiles[POLUS_MAX_GROUP], tile0[POLUS_MAX_GROUP + 1], unit0[POLUS_MAX_GROUP + 1];
+    int n, base, kr, krem, R, q_units, rem_units, slots, grid, ttot;
+};
+int polus_ppks_sk_plan(const int* n_out, const int* n_in, int n, int T, int ncu, int delta, PPKSSKPlan* pl);
+int polus_launch_gemm_ppks_sk(const pgemm::GemmArgs* probs, const PPKSSKPlan& pl, float* slabs, float* const* cs, hipStream_t st);
+int polus_launch_dw_group_reduce_sk(const PPKSSKPlan& pl, const float* slabs, const float* const* cs, float* const* dW, float* const* db,
+                                    const long* lddw, const int* n_out, const int* n_in, int accumulate, hipStream_t st);

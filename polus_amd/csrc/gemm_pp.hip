@@ -331,14 +331,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
             bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
             bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
         };
-        // The prologue of this tile was issued before the previous tile's epilogue, whose stores are YOUNGER: an interior
-        // epilogue issues at least EPI_STORES vector-memory operations behind it (its C -- and pre-activation -- stores; the bias /
-        // aux / residual loads come on top), so "all but the EPI_STORES youngest" covers the prologue and lets the store tail
-        // drain under this tile's first K-tile instead of in front of it.  (Fewer younger operations than assumed would make the
-        // wait stricter, never laxer; an edge tile's epilogue has another count: full drain.)
-        constexpr int EPI_STORES = (MODE == 1 ? 2 : 1) * 16 * EpiCfg<WN>::PASSES;
+        // The prologue of this tile was issued before the previous tile's epilogue, whose stores are YOUNGER.  vmcnt retires in
+        // order, so `vmcnt(n)` covers the prologue exactly when the epilogue issued AT LEAST n vector-memory operations behind
+        // it: an interior epilogue issues 16 x PASSES C stores per wave, and as many pre-activation stores on top when MODE 1
+        // is given an aux buffer (the training forward; inference and the frozen encoders pass none).  The bias / aux /
+        // residual loads only add to that.  A larger n than the operations really issued would reach INTO the prologue and let
+        // the first MFMAs read LDS before the DMA landed, so n is the guaranteed minimum of the launch, never more; an edge
+        // tile's epilogue has another count: full drain.
+        constexpr int C_STORES = 16 * EpiCfg<WN>::PASSES;
+        static_assert(2 * C_STORES <= 63, "vmcnt is a 6-bit counter");
         if (it == (int)blockIdx.x) { if (nk > 1) vmcnt<6>(); else vmcnt<0>(); }
-        else if (prev_interior && !(p.ablate & 128)) vmcnt<(EPI_STORES < 60 ? EPI_STORES : 60)>();
+        else if (prev_interior && !(p.ablate & 128)) { if (MODE == 1 && p.aux) vmcnt<2 * C_STORES>(); else vmcnt<C_STORES>(); }
         else vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind

@@ -43,18 +43,17 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <int N> __device__ __forceinline__ void vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-__device__ __forceinline__ void ppks_body(const GemmArgs& p, const int wg_in, const int nwg, const int split) {
+// One 256 x 256 tile of dW over the contraction rows [kbeg, kend) (whole K-tiles).  `C` / `ldc`: where the tile's f32 values go,
+// addressed by ABSOLUTE (m, n) -- a slab of the problem's shape, dW itself, or a dense tile slab offset by its origin;
+// `csum_out`: this slice's row of column sums (bias gradient), indexed by absolute m, or null.
+__device__ __forceinline__ void ppks_body(const GemmArgs& p, const int m0, const int n0, const int kbeg, const int kend,
+                                          float* C, const long ldc, float* csum_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int wm = wid >> 2, wn = wid & 3;
 
-    const int tiles_n = (p.N + TN - 1) / TN;
-    const int wg = xcd_remap(wg_in, nwg);
-    const int m0 = (wg / tiles_n) * TM, n0 = (wg % tiles_n) * TN;
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
     const int NP = (kend - kbeg) / 32;                 // phases (K-halves); even: k ranges are whole K-tiles
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_chunk_ppks);
 
@@ -96,7 +95,7 @@ __device__ __forceinline__ void ppks_body(const GemmArgs& p, const int wg_in, co
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool want_colsum = p.colsum_a != nullptr && n0 == 0;
+    const bool want_colsum = csum_out != nullptr && n0 == 0;
     f32x4 csum[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     Frag<bf16_t> ones;
 #pragma unroll
@@ -162,31 +161,35 @@ __device__ __forceinline__ void ppks_body(const GemmArgs& p, const int wg_in, co
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int m = m0 + wm * 128 + (2 * wn + e) * 16 + i;
-            if (m < p.M) p.colsum_a[(long)split * p.M + m] = csum[e][0];
+            if (m < p.M) csum_out[m] = csum[e][0];
         }
     }
     GemmArgs q = p;
-    q.C = static_cast<float*>(p.C) + (long)split * p.c_split_stride;
+    q.C = C; q.ldc = ldc;
     epilogue_wave_128x64_lds<float, false>(q, acc, m0 + wm * 128, n0 + wn * 64, lane, smem + wid * 8704);
 }
 
 struct PPKSGroupArgs {
     GemmArgs p[POLUS_MAX_GROUP];
-    int wg0[POLUS_MAX_GROUP + 1];     // first workgroup of each problem, ascending
-    int tiles[POLUS_MAX_GROUP];       // real tiles of each problem
-    int tpad[POLUS_MAX_GROUP];        // tiles rounded up to a multiple of 8 (workgroup index mod 8 stays the XCD)
+    int unit0[POLUS_MAX_GROUP + 1];   // first work unit of each problem, ascending; a problem's units = its K-slices x its tiles, slice-major
+    int tiles[POLUS_MAX_GROUP];       // tiles of each problem
     int n;
 };
 
+// Work unit of workgroup b: the hardware deals workgroups to the 8 XCDs round-robin, and xcd_remap gives every XCD a contiguous
+// run of the unit list -- consecutive tiles of one problem and one K-slice, which walk K in step and share their operand panels
+// through that XCD's L2 -- of the SAME length on every XCD (+-1).  (Rounds 1-3 padded every problem's tile list to a multiple of
+// 8 instead: 216 units then fell 32 / 30 / 30 / 28 / 24 / 24 / 24 / 24 on the XCDs.  A kernel on another stream is dealt to the
+// XCDs round-robin as well and its dispatch stops at the first XCD without a free CU, so beside that layout the LayerNorm
+// backward of the next layer did not start before the weight gradients had finished -- tools/exp/shadow_probe.py.)
 __global__ __launch_bounds__(NTHR, 2) void gemm_ppks_grouped_kernel(PPKSGroupArgs ga) {
-    const int b = blockIdx.x;
+    const int unit = xcd_remap(blockIdx.x, gridDim.x);
     int q = 0;
 #pragma unroll
     for (int k = 1; k < POLUS_MAX_GROUP; ++k)
-        if (k < ga.n && b >= ga.wg0[k]) q = k;
-    const int rel = b - ga.wg0[q];
-    const int split = rel / ga.tpad[q], wg = rel - split * ga.tpad[q];
-    if (wg >= ga.tiles[q]) return;          // padding workgroup
+        if (k < ga.n && unit >= ga.unit0[k]) q = k;
+    const int rel = unit - ga.unit0[q];
+    const int split = rel / ga.tiles[q], tile = rel - split * ga.tiles[q];
     // the chosen problem's arguments straight out of the kernarg segment (a run-time index into the by-value
     // array would go through scratch)
     typedef const __attribute__((address_space(4))) unsigned char* karg_t;
@@ -205,7 +208,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppks_grouped_kernel(PPKSGroupArg
         P.bias = nullptr; P.resid = nullptr; P.aux = nullptr; P.partial = nullptr;
         P.colsum_a = (float*)(gfloat_t*)P.colsum_a;
     }
-    ppks_body(P, wg, ga.tiles[q], split);
+    const int tiles_n = (P.N + TN - 1) / TN;
+    const int kbeg = split * P.k_per_split;
+    ppks_body(P, (tile / tiles_n) * TM, (tile % tiles_n) * TN, kbeg, min(P.K, kbeg + P.k_per_split),
+              static_cast<float*>(P.C) + (long)split * P.c_split_stride, P.ldc,
+              P.colsum_a ? P.colsum_a + (long)split * P.M : nullptr);
 }
 
 // ---- one reduce launch for the whole group: dW = (dW +) sum_z slab[z] in slice order, db = (db +) sum_z colsum[z]
@@ -256,6 +263,147 @@ __global__ __launch_bounds__(256) void dw_group_reduce_kernel(DwReduceArgs ra) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stream-K hybrid of the grouped launch.  An encoder layer of BERT-base has 108 tiles; two K-slices each make 216 equal
+// workgroups on 256 CUs -- 40 CUs idle for the whole launch.  Here every tile still gets `base` regular slices (same
+// workgroup order as above, so the slices of one tile row walk K in step and share operands through their XCD's L2), but a
+// regular slice is only `kr` K-tiles long, base x kr < T / 64, and the K-tiles a tile is left short of are dealt, in
+// (tile, k) order, to the workgroups that are padding or absent above: each of those takes an equal run of that list
+// -- parts of two to four tiles, one prologue / epilogue per part.  kr is chosen so that all 256 workgroups carry the
+// same number of K-tiles (the remainder workgroups a few fewer: their extra epilogues).  Every part writes a dense
+// 256 x 256 f32 slab, slot = position of the part in the tile's K order; dw_group_reduce_sk_kernel adds a tile's slots in
+// that order, so the result does not depend on which CU ran what (bitwise reproducible, not bit-identical to the
+// two-slice form: another summation tree).
+struct PPKSSKArgs {
+    GemmArgs p[POLUS_MAX_GROUP];
+    int unit0[POLUS_MAX_GROUP + 1];   // first regular unit of each problem; a problem's regular units = base slices x its tiles, slice-major
+    int tiles[POLUS_MAX_GROUP];
+    int tile0[POLUS_MAX_GROUP + 1];   // first global tile of each problem (slab index)
+    float* cs[POLUS_MAX_GROUP];       // column sums [slots][M] per problem, or null
+    float* slabs;                     // [tiles of all problems][slots][256 x 256]
+    int n, base, kr, krem;            // regular slices per tile, K-tiles per regular slice, K-tiles per tile left over
+    int R, q_units, rem_units;        // remainder workgroups (units behind the regular ones); each takes q_units (+1 for the first rem_units) K-tiles of the left-over list
+    int slots, n_regular;             // n_regular = unit0[n]
+};
+
+// remainder workgroup that owns unit u of the left-over list
+__device__ __host__ __forceinline__ int sk_wg_of(int u, int q_units, int rem_units) {
+    const int big = rem_units * (q_units + 1);
+    return u < big ? u / (q_units + 1) : rem_units + (u - big) / q_units;
+}
+
+__global__ __launch_bounds__(NTHR, 2) void gemm_ppks_sk_kernel(PPKSSKArgs ga) {
+    const int unit = xcd_remap(blockIdx.x, gridDim.x);    // the same number of workgroups on every XCD (see gemm_ppks_grouped_kernel)
+    const int n_regular = ga.n_regular;
+    const bool regular = unit < n_regular;
+    int q = 0, tile = 0, kt0 = 0, kt1 = 0, slot = 0;      // current part: problem, tile in the problem, K-tiles [kt0, kt1), slab slot
+    int u = 0, u1 = 0, r = 0;                             // remainder workgroup r: units [u, u1) of the left-over list
+    if (regular) {
+#pragma unroll
+        for (int k = 1; k < POLUS_MAX_GROUP; ++k)
+            if (k < ga.n && unit >= ga.unit0[k]) q = k;
+        const int rel = unit - ga.unit0[q];
+        const int split = rel / ga.tiles[q];
+        tile = rel - split * ga.tiles[q];
+        kt0 = split * ga.kr; kt1 = kt0 + ga.kr; slot = split;
+    } else {
+        r = unit - n_regular;
+        if (r >= ga.R) return;
+        u = r * ga.q_units + min(r, ga.rem_units);
+        u1 = u + ga.q_units + (r < ga.rem_units ? 1 : 0);
+    }
+    typedef const __attribute__((address_space(4))) unsigned char* karg_t;
+    karg_t ka = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    for (;;) {
+        if (!regular) {
+            const int j = u / ga.krem, off = u - j * ga.krem;
+            const int len = min(ga.krem - off, u1 - u);
+            q = 0;
+#pragma unroll
+            for (int k = 1; k < POLUS_MAX_GROUP; ++k)
+                if (k < ga.n && j >= ga.tile0[k]) q = k;
+            tile = j - ga.tile0[q];
+            kt0 = ga.base * ga.kr + off; kt1 = kt0 + len;
+            slot = ga.base + (r - sk_wg_of(j * ga.krem, ga.q_units, ga.rem_units));
+            u += len;
+        }
+        GemmArgs P;
+        float* cs = nullptr;
+        {
+            static_assert(sizeof(GemmArgs) % 4 == 0, "GemmArgs is copied word by word");
+            const __attribute__((address_space(4))) uint32_t* sp =
+                reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(ka + offsetof(PPKSSKArgs, p) + (size_t)q * sizeof(GemmArgs));
+            uint32_t* d = reinterpret_cast<uint32_t*>(&P);
+#pragma unroll
+            for (int w = 0; w < (int)(sizeof(GemmArgs) / 4); ++w) d[w] = sp[w];
+            typedef __attribute__((address_space(1))) void gvoid_t;
+            P.A = (const void*)(const gvoid_t*)P.A; P.B = (const void*)(const gvoid_t*)P.B;
+            P.C = nullptr; P.bias = nullptr; P.resid = nullptr; P.aux = nullptr; P.partial = nullptr; P.colsum_a = nullptr;
+            P.flags = 0;
+#pragma unroll
+            for (int k = 0; k < POLUS_MAX_GROUP; ++k)
+                if (k == q) cs = ga.cs[k];
+        }
+        const int tiles_n = (P.N + TN - 1) / TN;
+        const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+        float* slab = ga.slabs + ((long)(ga.tile0[q] + tile) * ga.slots + slot) * (long)(TM * TN);
+        ppks_body(P, m0, n0, kt0 * TK, kt1 * TK, slab - ((long)m0 * TN + n0), TN, cs ? cs + (long)slot * P.M : nullptr);
+        if (regular || u >= u1) break;
+        __syncthreads();                                   // the epilogue's LDS staging is read before the next part's operands land on it
+    }
+}
+
+// dW = (dW +) sum of a tile's slab slots in K order; db likewise from the column sums of the tiles of the first tile column
+struct DwReduceSKArgs {
+    const float* slabs;
+    const float* cs[POLUS_MAX_GROUP];
+    float* dW[POLUS_MAX_GROUP];
+    float* db[POLUS_MAX_GROUP];
+    long lddw[POLUS_MAX_GROUP];
+    int n_out[POLUS_MAX_GROUP], n_in[POLUS_MAX_GROUP];
+    int tile0[POLUS_MAX_GROUP + 1];
+    int n, accumulate, base, krem, q_units, rem_units, slots;
+};
+
+__global__ __launch_bounds__(256) void dw_group_reduce_sk_kernel(DwReduceSKArgs ra) {
+    const int j = blockIdx.x >> 6, part = blockIdx.x & 63;        // 64 blocks of 4 rows x 256 columns per tile
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < POLUS_MAX_GROUP; ++k)
+        if (k < ra.n && j >= ra.tile0[k]) q = k;
+    const float* cs = nullptr; float* dW = nullptr; float* db = nullptr;
+    long lddw = 0; int n_out = 0, n_in = 0, t0 = 0;
+#pragma unroll
+    for (int k = 0; k < POLUS_MAX_GROUP; ++k)
+        if (k == q) { cs = ra.cs[k]; dW = ra.dW[k]; db = ra.db[k]; lddw = ra.lddw[k]; n_out = ra.n_out[k]; n_in = ra.n_in[k]; t0 = ra.tile0[k]; }
+    const int tiles_n = (n_in + TN - 1) / TN;
+    const int tile = j - t0;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    // slots of tile j: the regular slices, then one per remainder workgroup that holds a part of its left-over K-tiles
+    const int nslot = ra.base + sk_wg_of((j + 1) * ra.krem - 1, ra.q_units, ra.rem_units) - sk_wg_of(j * ra.krem, ra.q_units, ra.rem_units) + 1;
+    const int row = part * 4 + (threadIdx.x >> 6), col = (threadIdx.x & 63) * 4;
+    const float* src = ra.slabs + (long)j * ra.slots * (long)(TM * TN) + row * TN + col;
+    if (m0 + row < n_out && n0 + col < n_in) {
+        float4 s = *reinterpret_cast<const float4*>(src);
+        for (int z = 1; z < nslot; ++z) {
+            const float4 t = *reinterpret_cast<const float4*>(src + (long)z * (TM * TN));
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float4* c = reinterpret_cast<float4*>(dW + (long)(m0 + row) * lddw + n0 + col);
+        if (ra.accumulate) { const float4 o = *c; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        *c = s;
+    }
+    if (cs != nullptr && db != nullptr && n0 == 0 && part == 0) {
+        const int m = m0 + threadIdx.x;
+        if (m < n_out) {
+            float s = 0.f;
+            for (int z = 0; z < nslot; ++z) s += cs[(long)z * n_out + m];
+            db[m] = ra.accumulate ? db[m] + s : s;
+        }
+    }
+}
+
 }  // namespace
 
 // Tiles a problem contributes to the grouped launch (256 x 256).
@@ -273,17 +421,16 @@ int polus_launch_gemm_ppks_grouped_dw(const GemmArgs* probs, int n, const int* s
     PPKSGroupArgs ga;
     memset(&ga, 0, sizeof(ga));
     ga.n = n;
-    int t0 = 0;
+    int u0 = 0;
     for (int k = 0; k < n; ++k) {
         if (probs[k].K % TK != 0 || probs[k].k_per_split % TK != 0) return POLUS_ERR_INVALID;
         ga.p[k] = probs[k];
         ga.tiles[k] = polus_ppks_tiles(probs[k].M, probs[k].N);
-        ga.tpad[k] = (ga.tiles[k] + 7) / 8 * 8;
-        ga.wg0[k] = t0;
-        t0 += ga.tpad[k] * splits[k];
+        ga.unit0[k] = u0;
+        u0 += ga.tiles[k] * splits[k];
     }
-    ga.wg0[n] = t0;
-    hipLaunchKernelGGL(kern, dim3(t0), dim3(NTHR), SMEM, st, ga);
+    ga.unit0[n] = u0;
+    hipLaunchKernelGGL(kern, dim3(u0), dim3(NTHR), SMEM, st, ga);
     POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(ping-pong 256x256)");
     return POLUS_OK;
 }
@@ -307,5 +454,81 @@ int polus_launch_dw_group_reduce(int n, const float* const* slabs, const float* 
     if (b0 == 0) return POLUS_OK;
     hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(b0), dim3(256), 0, st, ra);
     POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(reduce)");
+    return POLUS_OK;
+}
+
+// ---- stream-K hybrid (see gemm_ppks_sk_kernel).  The plan is a pure function of the shapes and the CU count, so the
+// workspace query and the launch agree.
+int polus_ppks_sk_plan(const int* n_out, const int* n_in, int n, int T, int ncu, int delta, PPKSSKPlan* pl) {
+    memset(pl, 0, sizeof(*pl));
+    if (n < 1 || n > POLUS_MAX_GROUP || T % TK != 0 || ncu < 8) return 0;
+    const int nkt = T / TK;
+    int ttot = 0;
+    for (int k = 0; k < n; ++k) {
+        pl->tiles[k] = polus_ppks_tiles(n_out[k], n_in[k]);
+        pl->tile0[k] = ttot;
+        ttot += pl->tiles[k];
+    }
+    pl->tile0[n] = ttot;
+    const int base = ncu / ttot;
+    if (base < 1) return 0;
+    const int R = ncu - base * ttot;
+    if (R < 4) return 0;                              // (next to) no CU idle: the even split is as good
+    long units = (long)ttot * nkt;
+    int kr = (int)((units + ncu - 1) / ncu) + delta;
+    if (kr < 4 || base * kr >= nkt) return 0;
+    const int krem = nkt - base * kr;
+    const long rem_total = (long)ttot * krem;
+    if (rem_total < R) return 0;
+    pl->n = n; pl->base = base; pl->kr = kr; pl->krem = krem; pl->R = R;
+    pl->q_units = (int)(rem_total / R); pl->rem_units = (int)(rem_total % R);
+    // parts a tile's left-over K-tiles can fall into: ceil(krem / q) + 1 workgroups at most
+    pl->slots = base + (krem + pl->q_units - 1) / pl->q_units + 1;
+    int w = 0;
+    for (int k = 0; k < n; ++k) { pl->unit0[k] = w; w += pl->tiles[k] * base; }
+    pl->unit0[n] = w;
+    pl->grid = w + R;
+    pl->ttot = ttot;
+    return 1;
+}
+
+int polus_launch_gemm_ppks_sk(const GemmArgs* probs, const PPKSSKPlan& pl, float* slabs, float* const* cs, hipStream_t st) {
+    static bool attr_done = false;
+    auto kern = gemm_ppks_sk_kernel;
+    if (!attr_done) {
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_done = true;
+    }
+    PPKSSKArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    for (int k = 0; k < pl.n; ++k) {
+        if (probs[k].K % TK != 0) return POLUS_ERR_INVALID;
+        ga.p[k] = probs[k];
+        ga.unit0[k] = pl.unit0[k]; ga.tiles[k] = pl.tiles[k]; ga.tile0[k] = pl.tile0[k];
+        ga.cs[k] = cs[k];
+    }
+    ga.unit0[pl.n] = pl.unit0[pl.n]; ga.tile0[pl.n] = pl.tile0[pl.n];
+    ga.slabs = slabs;
+    ga.n = pl.n; ga.base = pl.base; ga.kr = pl.kr; ga.krem = pl.krem; ga.R = pl.R; ga.q_units = pl.q_units; ga.rem_units = pl.rem_units;
+    ga.slots = pl.slots; ga.n_regular = pl.unit0[pl.n];
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(NTHR), SMEM, st, ga);
+    POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(ping-pong 256x256, stream-K remainder)");
+    return POLUS_OK;
+}
+
+int polus_launch_dw_group_reduce_sk(const PPKSSKPlan& pl, const float* slabs, const float* const* cs, float* const* dW, float* const* db,
+                                    const long* lddw, const int* n_out, const int* n_in, int accumulate, hipStream_t st) {
+    DwReduceSKArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.slabs = slabs;
+    for (int k = 0; k < pl.n; ++k) {
+        ra.cs[k] = cs[k]; ra.dW[k] = dW[k]; ra.db[k] = db[k]; ra.lddw[k] = lddw[k]; ra.n_out[k] = n_out[k]; ra.n_in[k] = n_in[k];
+        ra.tile0[k] = pl.tile0[k];
+    }
+    ra.tile0[pl.n] = pl.tile0[pl.n];
+    ra.n = pl.n; ra.accumulate = accumulate; ra.base = pl.base; ra.krem = pl.krem; ra.q_units = pl.q_units; ra.rem_units = pl.rem_units;
+    ra.slots = pl.slots;
+    hipLaunchKernelGGL(dw_group_reduce_sk_kernel, dim3(pl.ttot * 64), dim3(256), 0, st, ra);
+    POLUS_CHECK_LAUNCH("polus_dense_bwd_params_grouped(reduce, stream-K slabs)");
     return POLUS_OK;
 }

@@ -24,7 +24,9 @@ for n_out, n_in in shapes:
 fl = sum(2.0 * T * o * i for o, i in shapes)
 fn = lambda: ops.dense_bwd_params_grouped(probs, False, 0)
 for name, env in (("ring, per-matrix reduce", {"POLUS_GEMM_PP": -1, "POLUS_DW_FUSED_REDUCE": 0}), ("ring, fused reduce", {"POLUS_GEMM_PP": -1}),
-                  ("ping-pong, fused reduce", {})):
+                  ("ping-pong, fused reduce", {}), ("ping-pong + stream-K remainder, delta 0", {"POLUS_DW_STREAMK": 1, "POLUS_DW_SK_DELTA": 0}),
+                  ("... delta 2", {"POLUS_DW_STREAMK": 1, "POLUS_DW_SK_DELTA": 2}), ("... delta 4", {"POLUS_DW_STREAMK": 1, "POLUS_DW_SK_DELTA": 4}),
+                  ("... delta 6", {"POLUS_DW_STREAMK": 1, "POLUS_DW_SK_DELTA": 6}), ("ping-pong, fused reduce (again)", {})):
     for k, v in env.items():
         ops.set_env(k, v)
     timed(fn, 3)

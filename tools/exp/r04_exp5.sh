@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04e5; rm -rf $O; mkdir -p $O
+export POLUS_UPDATE_AFTER_LN=0
+for rep in 1 2 3; do for v in "1 6" "0 6" "1 0" "2 6"; do set -- $v
+  POLUS_GEMM_PERSIST=$1 POLUS_GEMM_STAGGER_US=$2 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32-leg --no-loss100 2>/dev/null | python3 -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('persist $1 stagger $2 rep $rep: %.3f ms/step' % d['ms_per_step'])"
+done; done > $O/ab.txt
+cat $O/ab.txt

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--variants", default="-1,256,192")
     ap.add_argument("--ab", default=None, help="NAME=v1,v2,..: A/B another library switch (POLUS_GEMM_PP stays on its per-shape choice)")
+    ap.add_argument("--only", default=None, help="comma-separated substrings: only the shapes whose name contains one")
     ap.add_argument("--cold", action="store_true", help="touch 512 MiB between launches (operands no longer L2 / Infinity-Cache warm)")
     args = ap.parse_args()
     env_name = "POLUS_GEMM_PP"
@@ -60,6 +61,8 @@ def main():
     shapes = [("qkv fwd", 3 * H, H, "bias"), ("out fwd", H, H, "drop+resid"), ("ffn1 fwd", I, H, "gelu+aux"),
               ("ffn2 fwd", H, I, "drop+resid"), ("dx qkv", H, 3 * H, "resid"), ("dctx", H, H, "plain"),
               ("du (ffn2 dx)", I, H, "gelu-bwd"), ("da1 (ffn1 dx)", H, I, "resid")]
+    if args.only:
+        shapes = [sh for sh in shapes if any(o in sh[0] for o in args.only.split(","))]
     sels = [int(v) for v in args.variants.split(",")]
     label = (lambda s: 'ring' if s < 0 else 'pp' + str(s)) if not args.ab else (lambda s: f"{env_name[6:]}={s}")
     print(f"{'gemm':14s} {'N':>5s} {'K':>5s} {'epilogue':11s} " + " ".join(f"{label(s):>16s}" for s in sels))
