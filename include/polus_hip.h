@@ -135,6 +135,20 @@ size_t polus_dense_bwd_params_grouped_workspace_bytes(int n, const polus_dw_prob
 int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_problem* problems, int T, int accumulate,
                                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Dense layers with at most 8 output units (a token-classification head, polus/ner/models.py:26-44; the last layer of
+ * tutorials/classifier_example.py:44-48): y = x W^T + b, W [C][H] row-major in `dtype`.  HBM-bound, one wave per row, no matrix
+ * pipe: a 128-wide MFMA tile would compute 97 % padding.  polus_dense_thin_supported: 1 when (dtype, H, C) fits (C <= 8,
+ * H a multiple of 16 bytes of elements, H <= 1024).  forward: y [rows][C] in y_dtype (f32 or dtype).  backward: dy [rows][C] in
+ * dy_dtype (f32 or dtype); dx [rows][H] in dtype or NULL; dW [C][H] and db [C] (or NULL) f32, (+)= when accumulate; sums in a fixed
+ * order (bitwise reproducible); workspace from polus_dense_thin_bwd_workspace_bytes. */
+int polus_dense_thin_supported(int dtype, int H, int C);
+int polus_dense_thin_fwd(int dtype, const void* x, long ldx, const void* W, long ldw, const float* bias,
+                         int y_dtype, void* y, long ldy, int rows, int H, int C, void* stream);
+size_t polus_dense_thin_bwd_workspace_bytes(int dtype, int rows, int H, int C);
+int polus_dense_thin_bwd(int dtype, const void* x, long ldx, int dy_dtype, const void* dy, long lddy,
+                         const void* W, long ldw, void* dx, long lddx, float* dW, long lddw, float* db,
+                         int rows, int H, int C, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused scaled-dot-product attention (HF TFBertSelfAttention as driven by
  * TFBertSplited.call, polus/models.py:201-216, with the additive key mask
  * (1-m)*-10000 of polus/models.py:175-195).

@@ -71,6 +71,10 @@ SIGNATURES = {
     "polus_transpose_bf16_batched": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "polus_dense_bwd_params_grouped_workspace_bytes": (_sz, [_i, _vp, _i, _i]),
     "polus_dense_bwd_params_grouped": (_i, [_i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "polus_dense_thin_supported": (_i, [_i, _i, _i]),
+    "polus_dense_thin_fwd": (_i, [_i, _vp, _l, _vp, _l, _vp, _i, _vp, _l, _i, _i, _i, _vp]),
+    "polus_dense_thin_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "polus_dense_thin_bwd": (_i, [_i, _vp, _l, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "polus_comm_unique_id": (_i, [_vp]),
     "polus_comm_init": (_i, [_c.POINTER(_vp), _i, _i, _vp]),
     "polus_comm_destroy": (_i, [_vp]),

@@ -50,6 +50,7 @@ struct PolusCfg {
     int attn_fwd_dma;      // POLUS_ATTN_FWD_DMA: 1 (default) LDS-DMA / whole-row-softmax attention forward (bf16); 0 = the register-staged kernel
     int attn_bwd_kres;     // POLUS_ATTN_BWD_KRES: 1 (default) key-resident one-pass attention backward for bf16 sequences of several 256-key blocks, 2 = also at S = 256, 0 = never
     int attn_debug;        // POLUS_ATTN_DEBUG: diagnostics, parts of the key-resident attention backward switched off (wrong results)
+    int gemm_dynamic;      // POLUS_GEMM_DYNAMIC: 1 (default) the persistent ping-pong GEMM draws its tiles from per-XCD counters; 0 = dealt statically
     int dw_streamk;        // POLUS_DW_STREAMK: grouped dW with a stream-K remainder on the CUs the even K split leaves idle
     int dw_sk_cus;         // POLUS_DW_SK_CUS: CUs the stream-K grouped dW launch is planned for (0 = all that are not reserved)
     int dw_sk_delta;       // POLUS_DW_SK_DELTA: K-tiles a regular slice carries more than the even share (the remainder workgroups' extra epilogues)
@@ -57,6 +58,7 @@ struct PolusCfg {
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward (bf16): 64-key blocks by LDS-DMA at S = 256, 32-key blocks at S = 64 / 128, key-resident from S = 512; 2 / 3 force the 64- / 32-key-block kernel; 0 = two kernels
 };
 const PolusCfg& polus_cfg();
+unsigned* polus_tile_counters();   // a zeroed block of 16 counters in device memory for one persistent GEMM launch (rotating pool; the launch zeroes it again), or null
 int polus_reserved_cus();   // cfg.reserve_cus while the reserve is switched on (polus_set_reserve_active), else 0
 
 // ---------------------------------------------------------------- per-step scalars in device memory

@@ -464,6 +464,7 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
+    a.tile_ctr = nullptr;     // set by polus_launch_gemm_pp when it takes the persistent form
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
 template <int NT> struct PPPCfg {
     static constexpr int WN = 16 * NT;
     static constexpr int EPI = (EpiCfg<WN>::BYTES + 255) / 256 * 256;
-    static constexpr int SMEM = PPCfg<NT>::SMEM + 8 * EPI;
+    static constexpr int NEXT = PPCfg<NT>::SMEM + 8 * EPI;     // one word: the next tile's index, from the wave that drew it to the others
+    static constexpr int SMEM = NEXT + 16;
     static_assert(SMEM <= 160 * 1024, "two operand stages + the C staging of the 8 waves in one CU's LDS");
 };
 
@@ -296,6 +297,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
     const int a_off = (wm * 128 + i) * 128;
     const int b_off = A_REGION + (wn * WN + i) * 128;
 
+    // Tiles: workgroup b starts on tile b.  Statically (tile_ctr null) it goes on with b + grid, b + 2 grid, ...; dynamically the
+    // workgroups of an XCD (b & 7) draw the further tiles of that XCD's list {t : t & 7 == b & 7} -- the same tiles in the same
+    // order, so an XCD still works on a few operand panels at a time -- from a counter, one returning atomic per tile, issued
+    // at the head of the tile and read behind its K loop.  When such a launch shares the chip -- the dU launch starts on the CUs
+    // the weight-gradient launch of the layer above leaves free, 88 us before the rest become free -- the early workgroups keep
+    // drawing tiles instead of stopping after their three (rocprofv3 timeline, profiles/r04_*).  Which workgroup computes a tile
+    // does not change its value.
+    const int xcd = blockIdx.x & 7;
+    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;          // workgroups of this launch with the same b & 7
+    unsigned drawn = 0;
     int it = blockIdx.x, trow, tcol;
     bool prev_interior = false;
     tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
@@ -314,7 +325,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
         while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
     }
 
-    for (; it < ntiles; it += gridDim.x) {
+    for (; it < ntiles;) {
+        // (before the counted wait below: every vector-memory operation the K loop counts is younger than this one)
+        // (inline asm: hipcc's atomicAdd waits for the returned value -- vmcnt(0), the previous tile's store tail included -- on the spot)
+        if (p.tile_ctr && tid == 0)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(p.tile_ctr + xcd), "v"(1u) : "memory");
         f32x4 acc[8][NT];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
@@ -390,17 +405,34 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
         // every wave is done with both operand stages and no DMA is in flight: the next tile's operands start now
         const int cm0 = m0, cn0 = n0;
         prev_interior = p.epi_vec16 && (cm0 + TM <= p.M) && (cn0 + TN <= p.N);
+        int nxt = it + (int)gridDim.x;
+        if (p.tile_ctr) {
+            typedef __attribute__((address_space(3))) int lds_int_t;
+            volatile lds_int_t* slot = (volatile lds_int_t*)(smem + PPPCfg<NT>::NEXT);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) :: "memory");     // (nothing else is outstanding behind the K loop's tail)
+            if (tid == 0) *slot = 8 * (nwg_x + (int)drawn) + xcd;
+            __syncthreads();
+            nxt = *slot;
+        }
         // (the epilogue's bias / aux / residual loads are ordinary loads: hipcc waits vmcnt(0) at their first use while LDS-DMA
         // is in flight, i.e. for the prologue as well.  Issuing the prologue FIRST keeps both in flight together; issuing it
         // behind the bias loads -- so that the staging reads need not wait for it -- measured 5 % slower on the dU launch)
-        if (it + (int)gridDim.x < ntiles) {
-            tile_of(it + gridDim.x, ntiles, tiles_n, p.order, trow, tcol);
+        it = nxt;
+        if (it < ntiles) {
+            tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
             m0 = trow * TM; n0 = tcol * TN;
             set_tile(m0, n0);
             issue_prologue();
         }
         epilogue_wave<bf16_t, WN, DROP, MODE, false, (NT == 4 ? (MODE == 3 || DROP ? 1 : 2) : 4)>(
             p, acc, cm0 + wm * 128, cn0 + wn * WN, lane, smem + 2 * STAGE + wid * PPPCfg<NT>::EPI);
+    }
+    // the last workgroup out puts the counters back to zero for the next launch that is handed this block
+    if (p.tile_ctr && tid == 0) {
+        if (atomicInc(p.tile_ctr + 8, gridDim.x - 1) == gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) atomicExch(p.tile_ctr + x, 0u);
+        }
     }
 }
 
@@ -494,8 +526,10 @@ int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStrea
         // rounds, an epilogue too short to hide anything); POLUS_GEMM_PERSIST=2 forces it everywhere
         const bool wins = tn == 256 || a.persist_all;     // 192-wide launches lose with it (c5, 512 tiles of 256 x 192: 34.4 -> 34.8 ms/step)
         if (tiles > a.persist && wins) {
-            if (tn == 256) return launch_ppp_mode<4>(a, mode, drop, a.persist, st);
-            if (tn == 192) return launch_ppp_mode<3>(a, mode, drop, a.persist, st);
+            GemmArgs d = a;
+            d.tile_ctr = polus_cfg().gemm_dynamic ? polus_tile_counters() : nullptr;
+            if (tn == 256) return launch_ppp_mode<4>(d, mode, drop, a.persist, st);
+            if (tn == 192) return launch_ppp_mode<3>(d, mode, drop, a.persist, st);
         }
     }
     if (tn == 256) return launch_pp_mode<4>(a, mode, drop, st);

@@ -177,6 +177,14 @@ class Dense(Layer):
         odt = self.out_dtype or x2.dtype
         y = self._buf("y", (rows, self.units), odt, x2.device)
         bias = self.b.value if self.b is not None else None
+        # a handful of units (a classification head): HBM-bound wave-per-row kernels, no 128-wide MFMA tiles of padding
+        self._thin = (not self.activation and x2.is_cuda and x2.stride(1) == 1 and
+                      (x2.data_ptr() % 16 == 0) and ((x2.stride(0) * x2.element_size()) % 16 == 0) and
+                      os.environ.get("POLUS_DENSE_THIN", "1") != "0" and ops.dense_thin_supported(x2.dtype, self.in_features, self.units))
+        if self._thin:
+            ops.dense_thin_fwd(x2, self.w.compute, bias, y)
+            self._x = x2
+            return y.view(*lead, self.units)
         if self.activation:
             assert odt == x2.dtype, "an activated Dense keeps the compute dtype"
             u = self._buf("u", (rows, self.units), x2.dtype, x2.device)
@@ -191,6 +199,12 @@ class Dense(Layer):
         """dx_resid [rows, in] (row stride free): added to dX in the GEMM epilogue."""
         x = self._x
         dy2 = dy.reshape(-1, self.units)
+        if getattr(self, "_thin", False) and dx_resid is None and dy2.dtype in (x.dtype, torch.float32):
+            rows = x.shape[0]
+            dx = self._buf("dx", (rows, self.in_features), x.dtype, x.device) if need_dx else None
+            ops.dense_thin_bwd(x, dy2 if dy2.stride(1) == 1 else dy2.contiguous(), self.w.compute, dx, self.w.grad,
+                               self.b.grad if self.b is not None else None, accumulate)
+            return dx
         if dy2.dtype != x.dtype:  # f32 dlogits of an f32-output layer in bf16 mode
             d = self._buf("dy_cast", dy2.shape, x.dtype, x.device)
             ops.cast(dy2.contiguous(), d)

@@ -201,7 +201,7 @@ class BertLayer:
         self._stash = (x, mask, B, S, p_hid, p_att, seeds) if for_backward else None
         return y
 
-    def backward(self, dy, scratch, accumulate=False, side=None, after_ln2=None):
+    def backward(self, dy, scratch, accumulate=False, side=None):
         """dy [T,H] -> dx [T,H]; parameter gradients land in the arena (overwritten, or added
         to when `accumulate`).  `scratch(key, shape)` hands out buffers shared by all layers.
         The four weight gradients are ONE grouped launch (dense_bwd_params_grouped), queued once
@@ -234,8 +234,6 @@ class BertLayer:
         ops.layernorm_bwd(dy, bb["z2"], self.ln2_g.value, bb["m2"], bb["r2"], dz2,
                           self.ln2_g.grad, self.ln2_b.grad, self.ffn2_b.grad, accumulate,
                           dx_masked=dz2m, drop_p=p_hid, seed=seeds[2], partials=lnp[0] if lnp else None)
-        if after_ln2 is not None:
-            after_ln2()           # BertModel.backward: the optimizer update of the layer two above is queued behind this kernel
         dz2d = dz2m if dz2m is not None else dz2
         gemm_dx(dz2d, self.ffn2_w, du, aux=bb["u"], act="gelu", flags=ops.GEMM_ACT_BWD)
         gemm_dx(du, self.ffn1_w, da1, resid=dz2)
@@ -585,24 +583,10 @@ class BertModel(SavableModel):
             if lay.dw_done is not None:
                 main.wait_event(lay.dw_done)
             self._notify(lay.variables())
-        # The weight-gradient launch of the layer above holds 216 of the 256 CUs while this layer's first kernel, the
-        # LayerNorm backward, is queued behind it; the in-backward optimizer update of the layer two above (its gradients are
-        # final by now) would be dispatched at the same moment and fill the 40 free CUs with its own workgroups, so that
-        # the LayerNorm backward -- which the whole chain below waits for -- only finishes once the weight gradients
-        # have (rocprofv3 timeline: 255 us instead of 22).  Reporting the window BEHIND that kernel lets it have the free
-        # CUs first; the update still runs inside the same weight-gradient launch.  POLUS_UPDATE_AFTER_LN=0: before it.
-        late = side is not None and os.environ.get("POLUS_UPDATE_AFTER_LN", "1") != "0"
         for l in reversed(self.layer):
-            hook = None
             if len(pending) == 2:      # this layer reuses the dY buffers of the layer two steps back
-                lay = pending.pop(0)
-                if late:
-                    if lay.dw_done is not None:
-                        main.wait_event(lay.dw_done)
-                    hook = (lambda la=lay: self._notify(la.variables()))
-                else:
-                    retire(lay)
-            dy = l.backward(dy, self.scratch, accumulate, side, after_ln2=hook)
+                retire(pending.pop(0))
+            dy = l.backward(dy, self.scratch, accumulate, side)
             pending.append(l)
         for lay in pending:
             retire(lay)

@@ -405,6 +405,37 @@ def dense_bwd_params_grouped(problems, accumulate=False, split_k=1):
         prof.append(("dw", sum(2.0 * T * p[0].shape[1] * p[1].shape[1] for p in problems), e0, e1))
 
 
+def dense_thin_supported(dtype, H, C):
+    """A Dense with at most 8 units takes the HBM-bound wave-per-row kernels instead of MFMA tiles (include/polus_hip.h)."""
+    return bool(_lib.load().polus_dense_thin_supported(dtype_code(dtype), int(H), int(C)))
+
+
+def dense_thin_fwd(x, w, bias, y):
+    """y [rows, C] = x [rows, H] . w [C, H]^T + bias; y in f32 or x's dtype."""
+    _req_cuda(x, w, bias, y)
+    rows, H = x.shape
+    C = w.shape[0]
+    assert w.dtype == x.dtype and w.shape[1] == H and y.shape == (rows, C)
+    assert x.stride(1) == 1 and w.stride(1) == 1 and y.stride(1) == 1
+    check(_lib.load().polus_dense_thin_fwd(dtype_code(x.dtype), ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias),
+                                           dtype_code(y.dtype), ptr(y), y.stride(0), rows, H, C, _st()), "polus_dense_thin_fwd")
+
+
+def dense_thin_bwd(x, dy, w, dx, dw, db, accumulate=False):
+    """dx [rows, H] = dy . w (dx None: skipped), dw [C, H] (+)= dy^T x, db [C] (+)= colsum(dy): one pass over x."""
+    lib = _lib.load()
+    _req_cuda(x, dy, w, dx, dw, db)
+    rows, H = x.shape
+    C = w.shape[0]
+    assert dy.shape == (rows, C) and dy.stride(1) == 1 and dw.dtype == torch.float32 and tuple(dw.shape) == (C, H) and dw.stride(1) == 1
+    assert dx is None or (dx.dtype == x.dtype and dx.shape == x.shape and dx.stride(1) == 1)
+    nb = lib.polus_dense_thin_bwd_workspace_bytes(dtype_code(x.dtype), rows, H, C)
+    ws = workspace(x.device).get(nb)
+    check(lib.polus_dense_thin_bwd(dtype_code(x.dtype), ptr(x), x.stride(0), dtype_code(dy.dtype), ptr(dy), dy.stride(0),
+                                   ptr(w), w.stride(0), ptr(dx), dx.stride(0) if dx is not None else 0, ptr(dw), dw.stride(0), ptr(db),
+                                   rows, H, C, 1 if accumulate else 0, ptr(ws), ws.numel(), _st()), "polus_dense_thin_bwd")
+
+
 def transpose_bf16_batched(src_base, dst_base, segs_dev, nseg, total_tiles):
     """All matrices of a flat bf16 arena into its transposed twin in one launch (segs: int64 [nseg, 4])."""
     _req_cuda(src_base, dst_base, segs_dev)

@@ -671,6 +671,39 @@ def test_dense_bwd_params(ops, dtype, T, n_out, n_in, sk):
     assert_close(host(db), 2 * host(b0), 1e-6, "db accumulate")
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,H,C", [(16384, 768, 4), (1000, 1024, 8), (37, 128, 1), (513, 264, 3), (2048, 768, 5)])
+def test_dense_thin(ops, dt, rows, H, C):
+    """The wave-per-row kernels of a Dense with at most 8 units (a classification head): forward, and the one-pass backward
+    (dx, dW, db) against NumPy on the rounded operands; f32 and compute-dtype dy; dx skipped; accumulate; reproducible."""
+    if not ops.dense_thin_supported(dt, H, C):
+        pytest.skip("shape outside the thin kernels")
+    r = rng(rows + H + C)
+    X, W, b = r.standard_normal((rows, H)), r.standard_normal((C, H)) * 0.1, r.standard_normal(C)
+    dY = r.standard_normal((rows, C)) * 0.1
+    x_t, w_t, b_t = dev(X, dt), dev(W, dt), dev(b, torch.float32)
+    Xr, Wr = rounded(X, dt), rounded(W, dt)
+    for ydt in (torch.float32, dt):
+        y = torch.full((rows, C), float("nan"), dtype=ydt, device="cuda")
+        ops.dense_thin_fwd(x_t, w_t, b_t, y)
+        assert_close(host(y), Xr @ Wr.T + b, 2e-2 if ydt == torch.bfloat16 else 2e-5, "thin forward")
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-5
+    for dydt in (torch.float32, dt):
+        dy_t = dev(dY, dydt)
+        dYr = rounded(dY, dydt)
+        dx = torch.full((rows, H), float("nan"), dtype=dt, device="cuda")
+        dw, db = torch.full((C, H), float("nan"), device="cuda"), torch.full((C,), float("nan"), device="cuda")
+        ops.dense_thin_bwd(x_t, dy_t, w_t, dx, dw, db)
+        assert_close(host(dx), dYr @ Wr, tol, "thin dx")
+        assert_close(host(dw), dYr.T @ Xr, 2e-5, "thin dW")
+        assert_close(host(db), dYr.sum(0), 2e-5, "thin db")
+        dw2, db2 = torch.full_like(dw, float("nan")), torch.full_like(db, float("nan"))
+        ops.dense_thin_bwd(x_t, dy_t, w_t, None, dw2, db2)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2), "thin backward is not reproducible / depends on dx"
+        ops.dense_thin_bwd(x_t, dy_t, w_t, None, dw2, None, accumulate=True)
+        assert_close(host(dw2), 2 * host(dw), 1e-6, "thin dW accumulate")
+
+
 @pytest.mark.parametrize("T,shapes", [
     (16384, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),      # BERT-base layer: 108 tiles, 2 slices + 40 remainder workgroups
     (4096, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),       # 64 K-tiles: short slices, parts of one or two K-tiles
@@ -738,8 +771,11 @@ def test_gemm_pingpong_persistent_equals_per_tile(ops, tn, M, N, K):
     try:
         for kw in cases:
             outs = []
-            for pers in (2, 0):
+            # persistent with tiles drawn from the per-XCD counters (the default), persistent with tiles dealt statically, per tile;
+            # the first form twice: a launch must leave its counter block zeroed for the next one
+            for pers, dyn in ((2, 1), (2, 1), (2, 0), (0, 1)):
                 ops.set_env("POLUS_GEMM_PERSIST", pers)
+                ops.set_env("POLUS_GEMM_DYNAMIC", dyn)
                 out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
                 kw2 = dict(kw)
                 if kw2.get("aux") == "new":
@@ -747,11 +783,12 @@ def test_gemm_pingpong_persistent_equals_per_tile(ops, tn, M, N, K):
                 ops.gemm(a_t, b_t, out, **kw2)
                 outs.append((out, kw2.get("aux")))
             assert not torch.isnan(outs[0][0].float()).any()
-            assert torch.equal(outs[0][0], outs[1][0]), sorted(kw)
-            if kw.get("aux") == "new":
-                assert torch.equal(outs[0][1], outs[1][1])
+            for o in outs[1:]:
+                assert torch.equal(outs[0][0], o[0]), sorted(kw)
+                if kw.get("aux") == "new":
+                    assert torch.equal(outs[0][1], o[1])
     finally:
-        ops.set_env("POLUS_GEMM_PP"); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PERSIST")
+        ops.set_env("POLUS_GEMM_PP"); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PERSIST"); ops.set_env("POLUS_GEMM_DYNAMIC")
 
 
 @pytest.mark.parametrize("tn", [256, 192])
