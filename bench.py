@@ -247,12 +247,26 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
     # RCCL's channel kernels (untimed real training steps before the warm-up; every rank takes part)
     tuned = None
     if world > 1 and os.environ.get("POLUS_DP_TUNE", "1") != "0":
-        tick = [0]
+        prior = getattr(args, "dp_choice", None)
+        if prior is not None:
+            # a later leg of the same run (the f32 engine): the node has been measured once, take its choice over
+            trainer.reserve_cus_in_backward = prior["reserve_cus_in_backward"]
+            if "bucket_mb" in prior:
+                trainer.bucket_mb = prior["bucket_mb"]
+                trainer._reducers.clear()
+            tuned = dict(prior, reused_from_first_leg=True)
+        else:
+            tick = [0]
 
-        def tune_step():
-            tick[0] += 1
-            return one_step(10_000 + tick[0])
-        tuned = trainer.tune_data_parallel(tune_step, steps=4)
+            def tune_step():
+                tick[0] += 1
+                return one_step(10_000 + tick[0])
+            tuned = trainer.tune_data_parallel(tune_step, steps=4)
+            if tuned is not None:
+                # what the exchange actually ran with (comm.init may have set the first; the library reads the second)
+                tuned["NCCL_MAX_NCHANNELS"] = os.environ.get("NCCL_MAX_NCHANNELS")
+                tuned["POLUS_GEMM_RESERVE_CUS"] = os.environ.get("POLUS_GEMM_RESERVE_CUS")
+                args.dp_choice = {k: tuned[k] for k in ("reserve_cus_in_backward", "bucket_mb", "NCCL_MAX_NCHANNELS", "POLUS_GEMM_RESERVE_CUS") if k in tuned}
     first_loss = None
     for k in range(warmup):
         l = one_step(k)
@@ -487,6 +501,9 @@ def main():
             out["loss_at_step100"] = l100
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, L, H, A, I)
+        elif world > 1:
+            # timed on rank 0 at N = 1 only (a host-core measurement beside N busy ranks would be noise); same schema key
+            out["cpu_baseline"] = {"value": None, "note": "timed at N=1 only: see the cpu_baseline of the n_gpus=1 line of the same build"}
         print(json.dumps(out), flush=True)
     comm.barrier()
     comm.shutdown()

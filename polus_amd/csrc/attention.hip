@@ -1409,8 +1409,9 @@ int launch_fwd_dma(const AttnArgs& a, hipStream_t st) {
     auto kern = attn_fwd_dma_kernel<NW>;
     const size_t lds = FWD_RING * FWD_STAGE + (size_t)((a.S + 64 * NW - 1) / (64 * NW)) * 64 * NW * 4;
     static bool attr_done = false;
-    if (!attr_done) {
-        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!attr_done) {       // once, for the longest sequence the kernel takes (the key-bias block grows with S)
+        POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      FWD_RING * FWD_STAGE + (FWD_MAX_S + 64 * NW) * 4));
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((a.S + 16 * NW - 1) / (16 * NW), a.A, a.B), dim3(64 * NW), lds, st, a);
@@ -1441,10 +1442,7 @@ int launch_fused(const AttnArgs& a, int n_heads, int B, size_t lds, hipStream_t 
 template <int WHICH>
 int launch_wide(int dtype, const AttnArgs& a, hipStream_t st) {
     if (dtype != POLUS_BF16) return launch_wide_nw<WHICH, float, 4>(a, st);
-    const int forced = polus_cfg().attn_waves;
-    int nw = forced > 0 ? forced : (a.S >= 96 ? 8 : 4);
-    if (nw >= 16) return launch_wide_nw<WHICH, bf16_t, 16>(a, st);
-    if (nw >= 8) return launch_wide_nw<WHICH, bf16_t, 8>(a, st);
+    if (a.S >= 96) return launch_wide_nw<WHICH, bf16_t, 8>(a, st);
     return launch_wide_nw<WHICH, bf16_t, 4>(a, st);
 }
 }  // namespace
@@ -1462,7 +1460,7 @@ extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* ma
     a.drop_thresh = drop_p > 0.f ? polus_drop_thresh(drop_p) : 0u; a.drop_seed = seed; a.drop_inv = 1.0f / (1.0f - drop_p); a.dyn = polus_dyn();
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc2;
-    if (dtype == POLUS_BF16 && polus_cfg().attn_fwd_dma && S <= FWD_MAX_S)
+    if (dtype == POLUS_BF16 && S <= FWD_MAX_S)
         rc2 = S >= 96 ? launch_fwd_dma<8>(a, st) : launch_fwd_dma<4>(a, st);
     else
         rc2 = launch_wide<0>(dtype, a, st);
@@ -1475,7 +1473,7 @@ extern "C" int polus_attention_fwd(int dtype, const void* qkv, const int32_t* ma
 // ([S / 256][B S][H], key-resident one-pass backward)
 extern "C" size_t polus_attention_bwd_workspace_bytes(int B, int S, int n_heads) {
     size_t n = (size_t)B * S * n_heads * sizeof(float);
-    if (S > KR_KEYS && S % KR_KEYS == 0) n += (size_t)(S / KR_KEYS) * B * S * n_heads * D * sizeof(float);
+    if (S > KR_KEYS && S % KR_KEYS == 0 && S <= 2048) n += (size_t)(S / KR_KEYS) * B * S * n_heads * D * sizeof(float);      // (the key-resident kernel's range, polus_attention_bwd)
     return n;
 }
 
@@ -1522,20 +1520,19 @@ extern "C" int polus_attention_bwd(int dtype, const void* qkv, const int32_t* ma
         return POLUS_OK;
     }
     // query-resident one-pass forms: 64-key blocks by LDS-DMA at S = 256 (80.5 -> 76.8 us at 64 x 256, bit-identical), the 32-key-block
-    // kernel at S = 64 / 128 (20.9 against 22.5 us at 32 x 128); POLUS_ATTN_FUSED = 2 / 3 forces the former / the latter
+    // kernel at S = 64 / 128 (20.9 against 22.5 us at 32 x 128); the two were bit-identical where both ran (rounds 2-3)
     const int fused = polus_cfg().attn_fused;
-    if (dtype == POLUS_BF16 && (fused == 2 || (fused == 1 && S == 256)) && (S == 64 || S == 128 || S == 256)) {
+    if (dtype == POLUS_BF16 && fused && S == 256) {
         // one pass, one workgroup per (batch, head), 64-key blocks by LDS-DMA
-        int rc2 = S == 256 ? launch_q64<16>(a, n_heads, B, st) : S == 128 ? launch_q64<8>(a, n_heads, B, st) : launch_q64<4>(a, n_heads, B, st);
+        int rc2 = launch_q64<16>(a, n_heads, B, st);
         if (rc2 != POLUS_OK) return rc2;
         POLUS_CHECK_LAUNCH("polus_attention_bwd(one pass, 64-key blocks)");
         return POLUS_OK;
     }
-    if (dtype == POLUS_BF16 && polus_cfg().attn_fused && (S == 64 || S == 128 || S == 256)) {
+    if (dtype == POLUS_BF16 && fused && (S == 64 || S == 128)) {
         // one pass, one workgroup per (batch, head)
         const size_t lds = 2 * (size_t)S * TileCfg<bf16_t>::RS + 4 * (size_t)KBLK * TileCfg<bf16_t>::RS + 2 * (size_t)S * RSS + (size_t)S * 4;
-        int rc2 = S == 256 ? launch_fused<16>(a, n_heads, B, lds, st) : S == 128 ? launch_fused<8>(a, n_heads, B, lds, st)
-                                                                                   : launch_fused<4>(a, n_heads, B, lds, st);
+        int rc2 = S == 128 ? launch_fused<8>(a, n_heads, B, lds, st) : launch_fused<4>(a, n_heads, B, lds, st);
         if (rc2 != POLUS_OK) return rc2;
         POLUS_CHECK_LAUNCH("polus_attention_bwd(fused)");
         return POLUS_OK;

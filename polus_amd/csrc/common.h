@@ -33,10 +33,7 @@ static inline bool polus_aligned16(const void* p) { return (((uintptr_t)p) & 15)
 struct PolusCfg {
     int gemm_pp;           // POLUS_GEMM_PP: -1 off, 0 per-shape choice (default), 256 / 192 force that tile where legal
     int gemm_v1;           // POLUS_GEMM_V1: 128x128 register-staged kernel for everything
-    int ring_runtime_epi;  // POLUS_RING_RUNTIME_EPI: ring kernel with run-time epilogue flags (A/B)
     int dw_ungrouped;      // POLUS_DW_UNGROUPED: one dW launch per matrix
-    int ablate;            // POLUS_GEMM_ABLATE: diagnostics (bit0 no in-loop DMA, bit1 no MFMA)
-    int attn_waves;        // POLUS_ATTN_WAVES: 0 default
     int dw_fused_reduce;   // POLUS_DW_FUSED_REDUCE: 1 (default) one reduce launch per grouped dW
     int ln_bwd_blocks;     // POLUS_LN_BWD_BLOCKS: cap on LayerNorm-backward workgroups (default 512 = all resident at once; 1024 = round-1 grid)
     int ln_fin_single;     // POLUS_LN_FIN_SINGLE: LayerNorm-backward partials up to this many rows are reduced by one finalize launch, more in two stages (default 512)
@@ -47,7 +44,6 @@ struct PolusCfg {
     int gemm_order;        // POLUS_GEMM_ORDER: column tiles an XCD's concurrent ping-pong tiles span (0 = row-major run; default 4)
     int gemm_persist;      // POLUS_GEMM_PERSIST: 1 (default) = the multi-round 256-wide launches as one persistent workgroup per CU (next tile's prologue under the epilogue), 2 = every multi-round ping-pong launch, 0 = never
     int reserve_cus;       // POLUS_GEMM_RESERVE_CUS: CUs the tile-shape choice leaves to concurrent RCCL channel kernels (default 0)
-    int attn_fwd_dma;      // POLUS_ATTN_FWD_DMA: 1 (default) LDS-DMA / whole-row-softmax attention forward (bf16); 0 = the register-staged kernel
     int attn_bwd_kres;     // POLUS_ATTN_BWD_KRES: 1 (default) key-resident one-pass attention backward for bf16 sequences of several 256-key blocks, 2 = also at S = 256, 0 = never
     int attn_debug;        // POLUS_ATTN_DEBUG: diagnostics, parts of the key-resident attention backward switched off (wrong results)
     int gemm_dynamic;      // POLUS_GEMM_DYNAMIC: 1 (default) the persistent ping-pong GEMM draws its tiles from per-XCD counters; 0 = dealt statically
@@ -55,7 +51,7 @@ struct PolusCfg {
     int dw_sk_cus;         // POLUS_DW_SK_CUS: CUs the stream-K grouped dW launch is planned for (0 = all that are not reserved)
     int dw_sk_delta;       // POLUS_DW_SK_DELTA: K-tiles a regular slice carries more than the even share (the remainder workgroups' extra epilogues)
     int exp;               // POLUS_EXP: bit mask of experiments under measurement (tools/; every bit defaults to off)
-    int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward (bf16): 64-key blocks by LDS-DMA at S = 256, 32-key blocks at S = 64 / 128, key-resident from S = 512; 2 / 3 force the 64- / 32-key-block kernel; 0 = two kernels
+    int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward (bf16): 64-key blocks by LDS-DMA at S = 256, 32-key blocks at S = 64 / 128, key-resident from S = 512; 0 = two kernels
 };
 const PolusCfg& polus_cfg();
 unsigned* polus_tile_counters();   // a zeroed block of 16 counters in device memory for one persistent GEMM launch (rotating pool; the launch zeroes it again), or null

@@ -458,7 +458,6 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     if (resid) ev16 = ev16 && (((uintptr_t)resid) % 16 == 0) && ((ldr * es) % 16 == 0);
     if (aux) ev16 = ev16 && (((uintptr_t)aux) % 16 == 0) && ((ldaux * es) % 16 == 0);
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
-    a.ablate = polus_cfg().ablate;
     a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
     a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
@@ -612,7 +611,6 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     const int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     a.a_vec = a.b_vec = 1;
     a.colsum_a = cs_ws;
-    a.ablate = polus_cfg().ablate;
     a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
     a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
@@ -808,8 +806,6 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
     grouped_need(n, problems, splits, so, co);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     GemmArgs ga[POLUS_MAX_GROUP];
-    int ablate = 0;
-    ablate = polus_cfg().ablate;
     for (int k = 0; k < n; ++k) {
         const polus_dw_problem& q = problems[k];
         GemmArgs& a = ga[k];
@@ -819,7 +815,6 @@ extern "C" int polus_dense_bwd_params_grouped(int dtype, int n, const polus_dw_p
         a.k_per_split = kps[k];
         a.a_vec = a.b_vec = 1;
         a.colsum_a = q.db ? reinterpret_cast<float*>(ws + co[k]) : nullptr;
-        a.ablate = ablate;
         a.order = 0;
         a.persist = 0;
         a.persist_all = 0;

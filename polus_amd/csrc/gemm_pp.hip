@@ -62,10 +62,7 @@ template <int NT> struct PPCfg {
     static_assert(8 * ((EpiDbCfg<WN>::BYTES + 255) / 256 * 256) <= SMEM, "the C staging buffers of the 8 waves reuse the operand stages");
 };
 
-// ABL (diagnostics, POLUS_GEMM_ABLATE): bit0 = no LDS-DMA inside the K loop, bit1 = no MFMA, bit2 = no fragment reads,
-// bit3 = raised priority for the M sections instead of the R sections, bit4 = no epilogue,
-// bit6 = staggered start of half the first-round workgroups (bits 4 and 6: 256 x 256 tile only)
-template <int NT, bool DROP, int MODE, int ABL = 0>
+template <int NT, bool DROP, int MODE>
 __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     typedef PPCfg<NT> C;
     if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
@@ -76,14 +73,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     const int i = lane & 15, g = lane >> 4;
     const int wm = wid >> 2, wn = wid & 3;
 
-    if (ABL & 64) {
-        // diagnostics: every other first-round workgroup of an XCD starts (p.ablate >> 8) x 10 ns late, so that from
-        // then on half of the CUs reach their epilogues while the other half are inside their K loops
-        if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-            const unsigned long t0 = wall_clock64(), dt = (unsigned long)(p.ablate >> 8);
-            while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     const int tiles_n = (p.N + TN - 1) / TN;
     int trow, tcol;
     tile_of(blockIdx.x, gridDim.x, tiles_n, p.order, trow, tcol);
@@ -132,22 +121,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
     Frag<bf16_t> bfr[NT][2], af[2][2];         // af[m-tile of the phase][k-half]
     auto read_a = [&](int tile, int slab, int m) {
         const unsigned char* st = smem + (tile & 1) * STAGE + a_off + (2 * slab + m) * 2048;
-        if (ABL & 4) { asm volatile("" : "+v"(af[m][0].v), "+v"(af[m][1].v)); return; }
         af[m][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
         af[m][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
     };
     auto read_b = [&](int tile, int nt) {
         const unsigned char* st = smem + (tile & 1) * STAGE + b_off + nt * 2048;
-        if (ABL & 4) { asm volatile("" : "+v"(bfr[nt][0].v), "+v"(bfr[nt][1].v)); return; }
         bfr[nt][0].v = *reinterpret_cast<const bf16x8*>(st + c0);
         bfr[nt][1].v = *reinterpret_cast<const bf16x8*>(st + c1);
     };
-    if (ABL & 4) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bfr[nt][0].v = (bf16x8)(bf16_t)0.5f; bfr[nt][1].v = (bf16x8)(bf16_t)0.25f; }
-#pragma unroll
-        for (int m = 0; m < 2; ++m) { af[m][0].v = (bf16x8)(bf16_t)0.5f; af[m][1].v = (bf16x8)(bf16_t)0.25f; }
-    }
 
     // ---- prologue: all of tile 0, then what phases 1-3 of "tile -1" would have issued for tile 1
 #pragma unroll
@@ -169,35 +150,30 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
         constexpr int P = decltype(P_)::value, TAIL = decltype(TAIL_)::value;
         // R: this phase's fragments first -- their LDS latency passes under the LDS-DMA issue below --
         // then the refill of what the previous phase's reads released
-        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(2);
         if (P == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) read_b(t, nt);
         }
         read_a(t, P, 0);
         read_a(t, P, 1);
-        if (!(ABL & 1)) {
-            if (P == 0 && TAIL <= 1) { load_a(t + 1, 3); if (NB == 4) load_b(t + 1, 3); }
-            if (P >= 1 && TAIL == 0) { load_a(t + 2, P - 1); load_b(t + 2, P - 1); }
-        }
+        if (P == 0 && TAIL <= 1) { load_a(t + 1, 3); if (NB == 4) load_b(t + 1, 3); }
+        if (P >= 1 && TAIL == 0) { load_a(t + 2, P - 1); load_b(t + 2, P - 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers: their LDS region is free
         if (P == 3) {                                         // LDS-DMA data of the next K-tile has landed
             if (TAIL == 0) vmcnt<6>(); else vmcnt<0>();
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL & 8) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (ABL & 2) { asm volatile("" :: "v"(bfr[nt][0].v), "v"(bfr[nt][1].v), "v"(af[m][0].v), "v"(af[m][1].v)); continue; }
                 mma16(acc[2 * P + m][nt], bfr[nt][0], af[m][0]);
                 mma16(acc[2 * P + m][nt], bfr[nt][1], af[m][1]);
             }
-        if (ABL & 8) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -214,13 +190,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
 
     if (wm == 0) __builtin_amdgcn_s_barrier();             // pairs with group 1's last barrier (b)
     // every wave is done with the operand stages and no DMA is in flight: LDS now stages C
-    if (ABL & 16) {                                        // diagnostics: no epilogue (the accumulators stay live)
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < NT; ++b) asm volatile("" :: "v"(acc[a][b]));
-        return;
-    }
     // (two staging buffers per wave: bit-identical to the ring kernel's epilogue_wave, tests/test_kernels_gpu.py)
     epilogue_wave_db<bf16_t, WN, DROP, MODE>(p, acc, m0 + wm * 128, n0 + wn * WN, lane,
                                              smem + wid * ((EpiDbCfg<WN>::BYTES + 255) / 256 * 256));
@@ -242,17 +211,19 @@ template <int NT> struct PPPCfg {
     static_assert(SMEM <= 160 * 1024, "two operand stages + the C staging of the 8 waves in one CU's LDS");
 };
 
+// The persistent loop of one workgroup.  `vb` of `vgrid`: this workgroup's index among those that share its tile list
+// (vb & 7 = blockIdx.x & 7, the XCD); the list = the 256 x TN tiles of columns [n_lo, n_hi) of C, n_hi <= p.N (rows past
+// p.M and columns past p.N are clamped / skipped as in gemm_pp_kernel).  ctr / exit_ctr: see GemmArgs::tile_ctr.
 template <int NT, bool DROP, int MODE>
-__global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
+__device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgrid, const int n_lo, const int n_hi, unsigned* ctr) {
     typedef PPCfg<NT> C;
-    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
     constexpr int WN = C::WN, TN = C::TN, NB = C::NB, STAGE = C::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
     const int wm = wid >> 2, wn = wid & 3;
-    const int tiles_n = (p.N + TN - 1) / TN;
+    const int tiles_n = (n_hi - n_lo + TN - 1) / TN;
     const int ntiles = ((p.M + TM - 1) / TM) * tiles_n;
     const int nk = p.K / TK;
 
@@ -304,16 +275,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
     // the weight-gradient launch of the layer above leaves free, 88 us before the rest become free -- the early workgroups keep
     // drawing tiles instead of stopping after their three (rocprofv3 timeline, profiles/r04_*).  Which workgroup computes a tile
     // does not change its value.
-    const int xcd = blockIdx.x & 7;
-    const int nwg_x = ((int)gridDim.x - xcd + 7) >> 3;          // workgroups of this launch with the same b & 7
+    const int xcd = vb & 7;
+    const int nwg_x = (vgrid - xcd + 7) >> 3;                   // workgroups on this tile list with the same b & 7
     unsigned drawn = 0;
-    int it = blockIdx.x, trow, tcol;
+    int it = vb, trow, tcol;
     bool prev_interior = false;
+    if (it >= ntiles) return;
     tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
-    int m0 = trow * TM, n0 = tcol * TN;
+    int m0 = trow * TM, n0 = n_lo + tcol * TN;
     set_tile(m0, n0);
     issue_prologue();
-    if (p.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    if (p.stagger > 0 && ((vb >> 3) & 1)) {
         // Every other workgroup of an XCD starts p.stagger x 10 ns late (its first operands are already in flight).  All CUs
         // walk equal tiles in step, so their epilogues -- 64 MB of HBM traffic per round of tiles on the GELU launches -- would
         // all fall into the same few microseconds, in which no matrix instruction issues anywhere; half a phase apart, each
@@ -328,8 +300,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
     for (; it < ntiles;) {
         // (before the counted wait below: every vector-memory operation the K loop counts is younger than this one)
         // (inline asm: hipcc's atomicAdd waits for the returned value -- vmcnt(0), the previous tile's store tail included -- on the spot)
-        if (p.tile_ctr && tid == 0)
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(p.tile_ctr + xcd), "v"(1u) : "memory");
+        if (ctr && tid == 0)
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr + xcd), "v"(1u) : "memory");
         f32x4 acc[8][NT];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
@@ -355,8 +327,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
         // tile's epilogue has another count: full drain.
         constexpr int C_STORES = 16 * EpiCfg<WN>::PASSES;
         static_assert(2 * C_STORES <= 63, "vmcnt is a 6-bit counter");
-        if (it == (int)blockIdx.x) { if (nk > 1) vmcnt<6>(); else vmcnt<0>(); }
-        else if (prev_interior && !(p.ablate & 128)) { if (MODE == 1 && p.aux) vmcnt<2 * C_STORES>(); else vmcnt<C_STORES>(); }
+        if (it == vb) { if (nk > 1) vmcnt<6>(); else vmcnt<0>(); }
+        else if (prev_interior) { if (MODE == 1 && p.aux) vmcnt<2 * C_STORES>(); else vmcnt<C_STORES>(); }
         else vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind
@@ -405,8 +377,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
         // every wave is done with both operand stages and no DMA is in flight: the next tile's operands start now
         const int cm0 = m0, cn0 = n0;
         prev_interior = p.epi_vec16 && (cm0 + TM <= p.M) && (cn0 + TN <= p.N);
-        int nxt = it + (int)gridDim.x;
-        if (p.tile_ctr) {
+        int nxt = it + vgrid;
+        if (ctr) {
             typedef __attribute__((address_space(3))) int lds_int_t;
             volatile lds_int_t* slot = (volatile lds_int_t*)(smem + PPPCfg<NT>::NEXT);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) :: "memory");     // (nothing else is outstanding behind the K loop's tail)
@@ -420,20 +392,30 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
         it = nxt;
         if (it < ntiles) {
             tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
-            m0 = trow * TM; n0 = tcol * TN;
+            m0 = trow * TM; n0 = n_lo + tcol * TN;
             set_tile(m0, n0);
             issue_prologue();
         }
         epilogue_wave<bf16_t, WN, DROP, MODE, false, (NT == 4 ? (MODE == 3 || DROP ? 1 : 2) : 4)>(
             p, acc, cm0 + wm * 128, cn0 + wn * WN, lane, smem + 2 * STAGE + wid * PPPCfg<NT>::EPI);
     }
-    // the last workgroup out puts the counters back to zero for the next launch that is handed this block
-    if (p.tile_ctr && tid == 0) {
-        if (atomicInc(p.tile_ctr + 8, gridDim.x - 1) == gridDim.x - 1) {
+}
+
+// the last workgroup out puts the counters back to zero for the next launch that is handed this block
+__device__ __forceinline__ void ppp_release_counters(unsigned* tile_ctr) {
+    if (tile_ctr && threadIdx.x == 0) {
+        if (atomicInc(tile_ctr + 8, gridDim.x - 1) == gridDim.x - 1) {
 #pragma unroll
-            for (int x = 0; x < 8; ++x) atomicExch(p.tile_ctr + x, 0u);
+            for (int x = 0; x < 8; ++x) atomicExch(tile_ctr + x, 0u);
         }
     }
+}
+
+template <int NT, bool DROP, int MODE>
+__global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
+    if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
+    ppp_run<NT, DROP, MODE>(p, blockIdx.x, gridDim.x, 0, p.N, p.tile_ctr);
+    ppp_release_counters(p.tile_ctr);
 }
 
 template <int NT, bool DROP, int MODE>
@@ -460,11 +442,11 @@ int launch_ppp_mode(const GemmArgs& a, int mode, int drop, int ncu, hipStream_t 
     return POLUS_ERR_INVALID;
 }
 
-template <int NT, bool DROP, int MODE, int ABL = 0>
+template <int NT, bool DROP, int MODE>
 int launch_pp(const GemmArgs& a, hipStream_t st) {
     typedef PPCfg<NT> C;
     static bool attr_done = false;
-    auto kern = gemm_pp_kernel<NT, DROP, MODE, ABL>;
+    auto kern = gemm_pp_kernel<NT, DROP, MODE>;
     if (!attr_done) {
         POLUS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM));
@@ -478,31 +460,6 @@ int launch_pp(const GemmArgs& a, hipStream_t st) {
 
 template <int NT>
 int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
-    if (a.ablate && mode == 0) {
-        switch (a.ablate & 31) {
-            case 16: if constexpr (NT == 4) return launch_pp<NT, false, 0, 16>(a, st); else break;
-            case 23: if constexpr (NT == 4) return launch_pp<NT, false, 0, 23>(a, st); else break;
-            case 7: return launch_pp<NT, false, 0, 7>(a, st);
-            case 8: return launch_pp<NT, false, 0, 8>(a, st);
-            case 1: return launch_pp<NT, false, 0, 1>(a, st);
-            case 2: return launch_pp<NT, false, 0, 2>(a, st);
-            case 3: return launch_pp<NT, false, 0, 3>(a, st);
-            case 4: return launch_pp<NT, false, 0, 4>(a, st);
-            case 5: return launch_pp<NT, false, 0, 5>(a, st);
-            case 6: return launch_pp<NT, false, 0, 6>(a, st);
-            default: break;
-        }
-    }
-    if constexpr (NT == 4) {
-        if ((a.ablate & 255) == 64) {                      // staggered start (delay in bits 8..), tools/pp_stagger_probe.py
-            switch (mode) {
-                case 0: return launch_pp<NT, false, 0, 64>(a, st);
-                case 1: return launch_pp<NT, false, 1, 64>(a, st);
-                case 3: return launch_pp<NT, false, 3, 64>(a, st);
-                default: break;
-            }
-        }
-    }
     switch (mode) {
         case 0: return launch_pp<NT, false, 0>(a, st);
         case 1: return launch_pp<NT, false, 1>(a, st);
@@ -517,7 +474,7 @@ int launch_pp_mode(const GemmArgs& a, int mode, int drop, hipStream_t st) {
 // tn = 256 or 192; mode from polus_gemm_epi_mode (>= 0); K % 64 == 0; bf16 C; 16-byte aligned rows.
 int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStream_t st) {
     if (mode < 0 || a.K % TK != 0 || a.K < TK) return POLUS_ERR_INVALID;
-    if (a.persist > 0 && !(a.ablate & 127)) {
+    if (a.persist > 0) {
         // several rounds of tiles: one workgroup per CU walks them, the next tile's operand prologue under the epilogue
         const int tiles = ((a.M + TM - 1) / TM) * ((a.N + tn - 1) / tn);
         // measured (tools/pp_bench.py --ab POLUS_GEMM_PERSIST=0,1,2; bench.py --config c3 | c4 | c5): wins on the 256-wide launches --

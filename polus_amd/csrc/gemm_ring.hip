@@ -142,7 +142,7 @@ __device__ __forceinline__ void ring_body(const GemmArgs& p, const int wg_in, co
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
         const unsigned char* st = smem + stage * STAGE;
-        const bool dma = (t + 2 < nk) && !(p.ablate & 1);
+        const bool dma = t + 2 < nk;
         if (dma) issue(stage == 0 ? 2 : stage - 1, kbeg + (t + 2) * TK);   // stage read in step t-1
         Frag<bf16_t> af[8], bfr[4];
         typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -172,23 +172,16 @@ __device__ __forceinline__ void ring_body(const GemmArgs& p, const int wg_in, co
                 af[mt].v = __builtin_bit_cast(bf16x8, w);
             }
         }
-        if (p.ablate & 2) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) asm volatile("" :: "v"(af[mt].v));
+        for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) asm volatile("" :: "v"(bfr[nt].v));
-        } else {
-            __builtin_amdgcn_s_setprio(1);
+            for (int nt = 0; nt < 4; ++nt) mma16(acc[mt][nt], bfr[nt], af[mt]);
+        if (want_colsum) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) mma16(acc[mt][nt], bfr[nt], af[mt]);
-            if (want_colsum) {
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) mma16(csum[mt], ones, af[mt]);
-            }
-            __builtin_amdgcn_s_setprio(0);
+            for (int mt = 0; mt < 8; ++mt) mma16(csum[mt], ones, af[mt]);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (t + 1 < nk) {
             if (dma) POLUS_VMCNT(6); else POLUS_VMCNT(0);   // tile t+1 landed
             POLUS_LGKMCNT0();
@@ -436,12 +429,12 @@ int polus_launch_gemm_ring128(const GemmArgs& a, int mode, int drop, hipStream_t
 }
 
 int polus_launch_gemm_ring_dropout(const GemmArgs& a, hipStream_t st) {
-    if (polus_gemm_epi_mode(a, 0, 1) == 2 && !polus_cfg().ring_runtime_epi) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
+    if (polus_gemm_epi_mode(a, 0, 1) == 2) return launch_ring<bf16_t, false, false, true, 2>(a, 1, st);
     return launch_ring<bf16_t, false, false, true>(a, 1, st);
 }
 
 int polus_launch_gemm_ring(const GemmArgs& a, int c_is_f32, int a_ks, int b_ks, int splits, hipStream_t st) {
-    if (!c_is_f32 && !a_ks && !b_ks && splits == 1 && !polus_cfg().ring_runtime_epi) {
+    if (!c_is_f32 && !a_ks && !b_ks && splits == 1) {
         switch (polus_gemm_epi_mode(a, 0, 0)) {      // same epilogue classes as the persistent kernel
             case 0: return launch_ring<bf16_t, false, false, false, 0>(a, 1, st);
             case 1: return launch_ring<bf16_t, false, false, false, 1>(a, 1, st);

@@ -22,17 +22,13 @@ static int env_int(const char* name, int dflt) {
 static void read_cfg() {
     g_cfg.gemm_pp = env_int("POLUS_GEMM_PP", 0);
     g_cfg.gemm_v1 = getenv("POLUS_GEMM_V1") != nullptr;
-    g_cfg.ring_runtime_epi = getenv("POLUS_RING_RUNTIME_EPI") != nullptr;
     g_cfg.dw_ungrouped = getenv("POLUS_DW_UNGROUPED") != nullptr;
-    g_cfg.ablate = env_int("POLUS_GEMM_ABLATE", 0);
     g_cfg.gemm_order = env_int("POLUS_GEMM_ORDER", 4);
     g_cfg.gemm_stagger_us = env_int("POLUS_GEMM_STAGGER_US", 6);
     g_cfg.reserve_cus = env_int("POLUS_GEMM_RESERVE_CUS", 0);
     g_cfg.gemm_persist = env_int("POLUS_GEMM_PERSIST", 1);
-    g_cfg.attn_waves = env_int("POLUS_ATTN_WAVES", 0);
     g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
     g_cfg.attn_fused = env_int("POLUS_ATTN_FUSED", 1);
-    g_cfg.attn_fwd_dma = env_int("POLUS_ATTN_FWD_DMA", 1);
     g_cfg.attn_bwd_kres = env_int("POLUS_ATTN_BWD_KRES", 1);
     g_cfg.attn_debug = env_int("POLUS_ATTN_DEBUG", 0);
     g_cfg.ln_halfwave = env_int("POLUS_LN_HALFWAVE", 1);
@@ -63,7 +59,7 @@ int polus_reserved_cus() { return g_reserve_on ? polus_cfg().reserve_cus : 0; }
 // block zeroed (its last workgroup resets it), so a block is reusable as soon as the launch that held it has finished -- with
 // in-order streams 64 launches later it has, unless more than 64 persistent GEMMs are in flight at once.
 unsigned* polus_tile_counters() {
-    constexpr int MAXDEV = 16, SLOTS = 64, WORDS = 16;
+    constexpr int MAXDEV = 16, SLOTS = 64, WORDS = 16;     // 8 per-XCD tile counters, the exit counter at [8]
     static unsigned* pool[MAXDEV] = {nullptr};
     static unsigned next[MAXDEV] = {0};
     int dev = 0;

@@ -9,10 +9,12 @@ depend on that sample alone) and to size-independent properties otherwise.
   full depth  BERT-base L=12: f32 AND bf16 engines vs the oracle, every gradient, per element
 
 Tolerances.  f32 engine (exact-f32 MFMA; summation order is the only difference from the oracle):
-loss 2e-5, logits 1e-4 of max|ref|, gradients per element |a-r| <= 5e-4 |r| + 5e-4 rms(r).
+loss 2e-5, logits 1e-4 of max|ref|, gradients per element |a-r| <= 1.5e-5 |r| + 1.5e-5 rms(r) at full depth.
 bf16 engine (bf16 activations and weight shadows, f32 accumulation): loss 2e-2, logits 3e-2 of
 max|ref|, gradients cosine > 0.995 and norm within 3 % per tensor, per element
-|a-r| <= 0.1 |r| + 0.2 rms(r) (rms over the non-zero entries of r)."""
+|a-r| <= 0.09 |r| + 0.18 rms(r) (rms over the non-zero entries of r).
+The per-element bounds of the full-depth test are twice the worst ratio measured on MI355X in round 4 (the test prints the
+three worst tensors: f32 0.012 x (5e-4, 5e-4) at layer0.ffn2.w, bf16 0.43 x (0.1, 0.2) at emb.word)."""
 import numpy as np
 import pytest
 import torch
@@ -81,12 +83,14 @@ def test_full_depth_bert_base_matches_oracle(mode):
     for v in model.trainable_weights:
         got, ref = host(v.grad), og[v.name]
         if f32:
-            worst[v.name] = elem_err(got, ref, 5e-4, 5e-4)
+            worst[v.name] = elem_err(got, ref, 1.5e-5, 1.5e-5)
         else:
             n = np.linalg.norm(ref)
             if n > 1e-12 and v.size >= 256:
                 assert cosine(got, ref) > 0.995 and abs(np.linalg.norm(got) / n - 1) < 0.03, (v.name, cosine(got, ref), np.linalg.norm(got) / n)
-            worst[v.name] = elem_err(got, ref, 0.1, 0.2)
+            worst[v.name] = elem_err(got, ref, 0.09, 0.18)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(f"full depth, {mode}: worst per-element gradient error / bound: " + ", ".join(f"{k} {e:.3f}" for k, e in top))
     bad = {k: round(e, 3) for k, e in worst.items() if not e <= 1.0}
     assert not bad, f"{mode}: per-element gradient error beyond tolerance: {bad}"
 
@@ -122,17 +126,19 @@ def test_c2_bert_base_b32_s128_workload(mode):
 
 
 # ------------------------------------------------------------------------------ configs[2] anchor
-def test_c3_bert_base_b64_s256_logits_match_oracle():
-    """configs[2] per-GPU workload (64 x 256): f32-engine logits of two samples of the batch against the
-    oracle (tests/test_fullsize_gpu.py then ties the bf16 engine to this one at the same size)."""
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_c3_bert_base_b64_s256_logits_match_oracle(mode):
+    """configs[2] per-GPU workload (64 x 256), the shape bench.py's headline is quoted on: the logits of two samples of the
+    batch against the oracle, for BOTH engines (f32 1e-4, bf16 3e-2 of max|ref|); tests/test_fullsize_gpu.py adds the
+    engine-vs-engine and loss@step100 checks at the same size."""
     ocfg, params, hw, hb = oracle_setup()
     ids, mask, tt, labels = synth(64, 256, 11)
-    model = build(ocfg, params, hw, hb, "f32")
+    model = build(ocfg, params, hw, hb, mode)
     x, _ = dev_batch(ids, mask, tt, labels)
     logits = host(model(**x, training=False))
     pick = [3, 60]
     _, ref, _ = ob.token_classifier_fwd(params, ocfg, hw, hb, ids[pick], mask[pick], labels[pick], tt[pick])
-    assert_close(logits[pick], ref, 1e-4, "logits of samples 3, 60")
+    assert_close(logits[pick], ref, 1e-4 if mode == "f32" else 3e-2, f"logits of samples 3, 60 ({mode})")
 
 
 # ------------------------------------------------------------------------------ configs[4]
@@ -266,3 +272,41 @@ def test_c4_bert_large_dual_encoder_s512():
     print(f"c4 first-step loss: f32 {losses['f32']:.4f}  bf16 {losses['bf16']:.4f}  log(B) {np.log(B):.4f}")
     assert abs(losses["f32"] - np.log(B)) > 0.05, "scores too small: the in-batch loss would not see the encoders at all"
     assert abs(losses["bf16"] - losses["f32"]) < 5e-2 * max(1.0, abs(losses["f32"])), losses
+
+
+def test_c4_dual_encoder_at_the_benched_size():
+    """configs[3] at the size `bench.py --config c4` runs: 64 query-document pairs x 512 tokens, BERT-large.  The float64
+    oracle is out of reach here (64 x 512 x 24 layers), so: size-independent properties -- the bf16 engine's [CLS] states of all 64
+    queries against the f32 engine's (the oracle anchors of the test above tie that engine to the oracle at 1e-4), the
+    first-step losses of the two engines, and the encoder arena bit-unchanged by the training step (nothing is differentiated
+    through BERT, polus/ir/training.py:47-117)."""
+    from polus_amd.ir.models import DualEncoder
+    from polus_amd.ir.training import ContrastiveLoss, EfficientDenseRetrievalTrainer, InBatchDotScores
+    from polus_amd.optimizers import Adam
+    ocfg, params, _, _ = oracle_setup(large=True)
+    B, S, E = 64, 512, 128
+    qi, qm, _, _ = synth(B, S, 51)
+    di, dm, _, _ = synth(B, S, 52)
+    first = np.random.Generator(np.random.PCG64(53)).permutation(np.arange(2000, 2000 + 2 * B)).astype(np.int32)
+    qi[:, 0], di[:, 0] = first[:B], first[B:]                # input-specific first tokens (see the test above, Conditioning)
+    q = {"input_ids": torch.from_numpy(qi).cuda(), "attention_mask": torch.from_numpy(qm).cuda()}
+    d = {"input_ids": torch.from_numpy(di).cuda(), "attention_mask": torch.from_numpy(dm).cuda()}
+    pr = np.random.Generator(np.random.PCG64(54))
+    proj = [pr.standard_normal((E, ocfg.hidden_size)) * 0.013, np.zeros(E), pr.standard_normal((E, ocfg.hidden_size)) * 0.013, np.zeros(E)]
+    cls, losses = {}, {}
+    for mode in ("f32", "bf16"):
+        enc = build(ocfg, params, None, None, mode, num_labels=None)
+        cls[mode] = host(enc(**q, training=False).pooler_output).astype(np.float64)
+        model = DualEncoder(enc, projection_dim=E, compute_dtype=mode)
+        for v, a in zip(model.trainable_weights, proj):
+            v.assign(a.astype(np.float32))
+        before = enc.arena.params.clone()
+        trainer = EfficientDenseRetrievalTrainer(model, InBatchDotScores(), optimizer=Adam(1e-3), loss=ContrastiveLoss())
+        losses[mode] = float(trainer.train_step(q, d))
+        torch.cuda.synchronize()
+        assert torch.equal(before, enc.arena.params), f"the frozen encoder moved ({mode})"
+        del trainer, model, enc, before
+        torch.cuda.empty_cache()
+    assert_close(cls["bf16"], cls["f32"], 5e-2, "[CLS] states of the 64 queries, bf16 engine against f32 engine")
+    print(f"c4 at 64 x 512: first-step loss f32 {losses['f32']:.4f}  bf16 {losses['bf16']:.4f}  log(B) {np.log(B):.4f}")
+    assert np.isfinite(losses["f32"]) and abs(losses["bf16"] - losses["f32"]) < 5e-2 * max(1.0, abs(losses["f32"])), losses

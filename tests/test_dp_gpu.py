@@ -144,5 +144,7 @@ def test_bench_bare_multi_gpu_launch_line(tmp_path):
     t = out["dp_tuning"]
     assert t["reserve_on_ms"] > 0 and t["reserve_off_ms"] > 0
     assert t["reserve_cus_in_backward"] == (t["reserve_on_ms"] <= t["reserve_off_ms"])
+    assert "NCCL_MAX_NCHANNELS" in t and "POLUS_GEMM_RESERVE_CUS" in t       # the settings the exchange ran with, as used
+    assert out["cpu_baseline"]["value"] is None and "N=1" in out["cpu_baseline"]["note"]
     sizes = {mb: t[f"bucket_{mb}_ms"] for mb in (16, 32, 64, 128)}
     assert all(v > 0 for v in sizes.values()) and t["bucket_mb"] in sizes and sizes[t["bucket_mb"]] == min(sizes.values())

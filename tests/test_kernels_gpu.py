@@ -197,7 +197,7 @@ def test_attention_backward_one_pass_equals_two_kernel_form(ops, S, A, drop):
     outs = []
     ops.set_env("POLUS_ATTN_BWD_KRES", 0)            # the query-resident one-pass kernel (S = 256 would otherwise take the key-resident one)
     try:
-        for fused in (3, 0, 2):                       # 3: 32-key blocks, 0: two kernels, 2: 64-key blocks by LDS-DMA
+        for fused in (1, 0):                          # 1: one pass (32-key blocks at S = 64 / 128, 64-key blocks by LDS-DMA at 256), 0: two kernels
             ops.set_env("POLUS_ATTN_FUSED", fused)
             try:
                 d = torch.full((B * S, 3 * H), float("nan"), dtype=dt, device="cuda")
@@ -207,8 +207,6 @@ def test_attention_backward_one_pass_equals_two_kernel_form(ops, S, A, drop):
                 ops.set_env("POLUS_ATTN_FUSED")
         for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
             assert_close(outs[0][..., sl], outs[1][..., sl], 1.5e-2, nm)
-        # the 64-key-block kernel evaluates the same expressions and sums keys and queries in the same order: same bits
-        assert np.array_equal(outs[0], outs[2]), "attn_bwd_q64_kernel differs from attn_bwd_fused_kernel"
         # run-to-run bitwise identical
         d2 = torch.empty((B * S, 3 * H), dtype=dt, device="cuda")
         ops.attention_bwd(qkv_t, mask_t, ctx, dctx_t, lse, d2, B, S, A, drop_p=drop, seed=77)
@@ -750,7 +748,7 @@ def test_dense_bwd_params_grouped_streamk(ops, T, shapes):
 
 
 @pytest.mark.parametrize("tn", [256, 192])
-@pytest.mark.parametrize("M,N,K", [(1024, 3072, 768), (1280, 2304, 320), (1000, 1500, 64)])
+@pytest.mark.parametrize("M,N,K", [(1024, 3072, 768), (1280, 2304, 320), (1000, 1500, 64), (2048, 3072, 768), (2000, 3072, 320)])
 def test_gemm_pingpong_persistent_equals_per_tile(ops, tn, M, N, K):
     """gemm_ppp_kernel (one workgroup per CU walks several tiles, the next tile's operand prologue issued before the current
     epilogue) against the one-workgroup-per-tile launch: same MFMA order, same epilogue arithmetic -- bit-identical, for

@@ -1,5 +1,5 @@
 """Attention kernels of one BERT-base layer (B=64, S=256, A=12) with and without dropout; forward A/B of the LDS-DMA
-kernel against the register-staged one (POLUS_ATTN_FWD_DMA=0), interleaved rounds in one process.
+kernel, and the backward forms of the shape (the default one, and the alternatives POLUS_ATTN_BWD_KRES / POLUS_ATTN_FUSED select).
 
     python tools/attn_bench.py [--seq 256] [--batch 64]
 """
@@ -24,31 +24,17 @@ lse = torch.empty(B * A * S, dtype=torch.float32, device=dev)
 dqkv = torch.empty_like(qkv)
 for p in (0.0, 0.1):
     fwd = lambda: ops.attention_fwd(qkv, mask, ctx, lse, B, S, A, drop_p=p, seed=5)
-    t = {1: [], 0: []}
-    outs = {}
-    for rnd in range(5):
-        for v in (1, 0):
-            ops.set_env("POLUS_ATTN_FWD_DMA", v)
-            t[v].append(bench(fwd, 20))
-            if rnd == 0:
-                outs[v] = (ctx.float().clone(), lse.clone())
-    ops.set_env("POLUS_ATTN_FWD_DMA")
-    dc = (outs[1][0] - outs[0][0]).abs().max().item()
-    dl = (outs[1][1] - outs[0][1]).abs().max().item()
-    ops.set_env("POLUS_ATTN_BWD_KRES", 2)
-    tb = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
-    ops.set_env("POLUS_ATTN_BWD_KRES", 0)
-    ops.set_env("POLUS_ATTN_FUSED", 3)
-    tq = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
-    ops.set_env("POLUS_ATTN_FUSED", 2)
-    t64 = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20) if S in (64, 128, 256) else float("nan")
-    ops.set_env("POLUS_ATTN_FUSED")
-    ops.set_env("POLUS_ATTN_BWD_KRES")
-    t2 = None
+    bwd = lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5)
+    tf = [bench(fwd, 20) for _ in range(5)]
+    td = [bench(bwd, 20) for _ in range(5)]                    # the default backward of this shape
+    extra = ""
+    if S % 256 == 0 and S <= 2048:
+        ops.set_env("POLUS_ATTN_BWD_KRES", 2 if S == 256 else 0)     # the other one-pass form of this shape
+        extra += f"   bwd {'key-resident' if S == 256 else 'two kernels'} {bench(bwd, 20) * 1e6:.1f} us"
+        ops.set_env("POLUS_ATTN_BWD_KRES")
     if S in (64, 128, 256):
         ops.set_env("POLUS_ATTN_FUSED", 0)
-        t2 = bench(lambda: ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, B, S, A, drop_p=p, seed=5), 20)
+        extra += f"   bwd two kernels {bench(bwd, 20) * 1e6:.1f} us"
         ops.set_env("POLUS_ATTN_FUSED")
     med = lambda x: sorted(x)[len(x) // 2] * 1e6
-    print(f"B={B} S={S} drop_p={p}: fwd LDS-DMA {med(t[1]):.1f} us (min {min(t[1])*1e6:.1f})  register-staged {med(t[0]):.1f} us   "
-          f"|ctx diff| {dc:.2e} |lse diff| {dl:.2e}   bwd key-resident {tb*1e6:.1f} us (query-resident, 32-key blocks: {tq*1e6:.1f} us; 64-key blocks: {t64*1e6:.1f} us)" + (f"   bwd two kernels {t2*1e6:.1f} us" if t2 else ""), flush=True)
+    print(f"B={B} S={S} drop_p={p}: fwd {med(tf):.1f} us (min {min(tf) * 1e6:.1f})   bwd {med(td):.1f} us (min {min(td) * 1e6:.1f})" + extra, flush=True)

@@ -14,7 +14,7 @@ with tempfile.TemporaryDirectory() as td:
 bad = n = 0
 func = None
 for i, l in enumerate(lines):
-    m = re.match(r"^(_Z\S*gemm_ppp_kernel\S*):", l)
+    m = re.match(r"^(_Z\S*gemm_pp[pm]_kernel\S*):", l)
     if m:
         func = m.group(1)
     m = re.search(r"global_atomic_add (v\d+), ", l)

@@ -44,7 +44,9 @@ def timed(fn, iters=6):
     return e0.elapsed_time(e1) / iters * 1e3
 
 for name, env in (("even split, 216 workgroups", {}), ("stream-K plan for 208 CUs", {"POLUS_DW_STREAMK": 1, "POLUS_DW_SK_CUS": 208}),
-                  ("ln_bwd grid 256", {"POLUS_LN_BWD_BLOCKS": 256}), ("ln_bwd grid 1024", {"POLUS_LN_BWD_BLOCKS": 1024})):
+                  ("ln_bwd grid 256", {"POLUS_LN_BWD_BLOCKS": 256}), ("ln_bwd grid 1024", {"POLUS_LN_BWD_BLOCKS": 1024}),
+                  ("wave-per-row ln_bwd", {"POLUS_LN_HALFWAVE": 0}), ("wave-per-row, grid 1024", {"POLUS_LN_HALFWAVE": 0, "POLUS_LN_BWD_BLOCKS": 1024}),
+                  ("even split again", {})):
     for k, val in env.items():
         ops.set_env(k, val)
     a, b, c = (min(timed(f) for _ in range(3)) for f in (dw, ln, both))
