@@ -408,7 +408,7 @@ class GradBucketReducer:
     mode "allreduce": buckets cut at the given tensor `boundaries` (sorted offsets), ~bucket_bytes each.
     mode "rs": buckets of equal size (a multiple of 64 * world elements, so that every slice is whole
     256-byte lines), the front bucket takes the remainder; `grads.numel()` must be a multiple of 64 * world
-    (ParamArena pads to that).  `transport_dtype=torch.bfloat16` sends the gradients as bf16."""
+    (ParamArena pads to 64 * 1680 elements: every world size up to 8, and 16; other sizes fall back to all-reduce with a warning).  `transport_dtype=torch.bfloat16` sends the gradients as bf16."""
 
     def __init__(self, grads, bucket_bytes=64 << 20, boundaries=None, mode="allreduce", transport_dtype=None, plane=None):
         self.grads = grads

@@ -55,6 +55,7 @@ struct PolusCfg {
 };
 const PolusCfg& polus_cfg();
 unsigned* polus_tile_counters();   // a zeroed block of 16 counters in device memory for one persistent GEMM launch (rotating pool; the launch zeroes it again), or null
+int polus_num_cus();        // CUs of the current device
 int polus_reserved_cus();   // cfg.reserve_cus while the reserve is switched on (polus_set_reserve_active), else 0
 
 // ---------------------------------------------------------------- per-step scalars in device memory

@@ -285,15 +285,6 @@ extern "C" size_t polus_gemm_workspace_bytes(int M, int N, int split_k) {
     return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
 }
 
-static int polus_num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
 // Epilogue class of a bf16-C launch for the kernels with compile-time epilogues (gemm_pp.hip, the 128 x 128 ring tile):
 // 0 = alpha / bias, 1 = activation forward (+ pre-activation to aux), 2 = residual (+ dropout), 3 = activation backward
 // (aux read); -1 = a combination they are not built for (the caller stays on the run-time epilogue of the ring kernel).

@@ -51,6 +51,15 @@ extern "C" int polus_reload_env(void) { read_cfg(); return POLUS_OK; }
 
 // The CU reserve only pays while a collective's channel kernels are resident: the trainer switches it on around backward
 // (where the bucketed exchange runs) and off for the forward pass, which shares the chip with nothing.
+int polus_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 static int g_reserve_on = 1;
 extern "C" int polus_set_reserve_active(int on) { g_reserve_on = on != 0; return POLUS_OK; }
 int polus_reserved_cus() { return g_reserve_on ? polus_cfg().reserve_cus : 0; }

@@ -143,12 +143,12 @@ class ParamArena:
         if self.params is not None:
             return self
         from . import ops
-        # whole 256-byte lines per rank for every world size up to 8 (840 = lcm(1..8)): a gradient reduce-scatter
+        # whole 256-byte lines per rank for every world size up to 8, and 16 (1680 = lcm(1..8, 16)): a gradient reduce-scatter
         # cuts the arena into `world` equal slices.  The unit does not depend on the world size the process happens
         # to run in (nor on whether comm was initialised before the model was built), so the arena of a model has ONE
         # size: a training state saved on N GPUs resumes on any other N.  `extent` = the end of the last variable.
         self.extent = self.size
-        q = ALIGN * 840
+        q = ALIGN * 1680
         self.size = (self.size + q - 1) // q * q
         host = np.zeros(self.size, np.float32)
         for v in self.vars:

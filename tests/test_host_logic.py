@@ -340,7 +340,7 @@ def test_bucket_plan_of_bert_base_at_world_8(monkeypatch, bucket_mb):
     for sz in sizes:
         offs.append(n)
         n += (sz + 63) // 64 * 64
-    n = (n + 64 * 840 - 1) // (64 * 840) * (64 * 840)           # ParamArena's world-independent padding
+    n = (n + 64 * 1680 - 1) // (64 * 1680) * (64 * 1680)        # ParamArena's world-independent padding
     grads = torch.empty(n, dtype=torch.float32, device="meta")
     elems = (bucket_mb << 20) // 4
     for mode in ("rs", "allreduce"):
