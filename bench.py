@@ -364,7 +364,7 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
 
 
 LOSS100_FIXTURE = os.path.join(ROOT, "tests", "golden", "loss100_bert_base_b64_s256.npz")
-TRAFFIC_PROFILE = "r03_gemm_hbm_traffic.json"
+TRAFFIC_PROFILE = "r04_gemm_hbm_traffic.json"
 
 
 def loss_at_step100(args, rank):

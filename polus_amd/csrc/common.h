@@ -40,13 +40,11 @@ struct PolusCfg {
     int gemm_ring128;      // POLUS_GEMM_RING128: -1 never, 0 (default) where the heuristic picks it, 1 wherever it applies (bf16 C, K-contiguous operands)
     int gemm_auto_split;   // POLUS_GEMM_AUTO_SPLIT: 1 (default) polus_gemm_auto_split recommends K slices for under-filled bf16 Dense GEMMs; 0 = always 1
     int ln_halfwave;       // POLUS_LN_HALFWAVE: 1 (default) half-wave-per-row LayerNorm kernels with 16-byte accesses (bf16, H % 256 == 0)
-    int gemm_stagger_us;   // POLUS_GEMM_STAGGER_US: start delay of every other workgroup of the persistent ping-pong GEMM (default 6, 0 = none)
     int gemm_order;        // POLUS_GEMM_ORDER: column tiles an XCD's concurrent ping-pong tiles span (0 = row-major run; default 4)
     int gemm_persist;      // POLUS_GEMM_PERSIST: 1 (default) = the multi-round 256-wide launches as one persistent workgroup per CU (next tile's prologue under the epilogue), 2 = every multi-round ping-pong launch, 0 = never
     int reserve_cus;       // POLUS_GEMM_RESERVE_CUS: CUs the tile-shape choice leaves to concurrent RCCL channel kernels (default 0)
     int attn_bwd_kres;     // POLUS_ATTN_BWD_KRES: 1 (default) key-resident one-pass attention backward for bf16 sequences of several 256-key blocks, 2 = also at S = 256, 0 = never
     int attn_debug;        // POLUS_ATTN_DEBUG: diagnostics, parts of the key-resident attention backward switched off (wrong results)
-    int gemm_dynamic;      // POLUS_GEMM_DYNAMIC: 1 (default) the persistent ping-pong GEMM draws its tiles from per-XCD counters; 0 = dealt statically
     int dw_streamk;        // POLUS_DW_STREAMK: grouped dW with a stream-K remainder on the CUs the even K split leaves idle
     int dw_sk_cus;         // POLUS_DW_SK_CUS: CUs the stream-K grouped dW launch is planned for (0 = all that are not reserved)
     int dw_sk_delta;       // POLUS_DW_SK_DELTA: K-tiles a regular slice carries more than the even share (the remainder workgroups' extra epilogues)
@@ -54,7 +52,6 @@ struct PolusCfg {
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward (bf16): 64-key blocks by LDS-DMA at S = 256, 32-key blocks at S = 64 / 128, key-resident from S = 512; 0 = two kernels
 };
 const PolusCfg& polus_cfg();
-unsigned* polus_tile_counters();   // a zeroed block of 16 counters in device memory for one persistent GEMM launch (rotating pool; the launch zeroes it again), or null
 int polus_num_cus();        // CUs of the current device
 int polus_reserved_cus();   // cfg.reserve_cus while the reserve is switched on (polus_set_reserve_active), else 0
 

@@ -451,10 +451,8 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
     a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
-    a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
-    a.tile_ctr = nullptr;     // set by polus_launch_gemm_pp when it takes the persistent form
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     dim3 grid(tiles, 1, split_k > 1 ? splits_eff : 1);
@@ -604,7 +602,6 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     a.colsum_a = cs_ws;
     a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
-    a.stagger = polus_cfg().gemm_stagger_us > 0 ? polus_cfg().gemm_stagger_us * 100 : 0;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
     int rc;

@@ -27,8 +27,6 @@ struct GemmArgs {
     int persist_all;  // POLUS_GEMM_PERSIST=2: the persistent form for every multi-round ping-pong launch (A/B)
     int persist; // gemm_pp.hip: > 0 = number of CUs for the persistent form of multi-round launches (POLUS_GEMM_PERSIST), 0 = one workgroup per tile
     int order;   // gemm_pp.hip: column tiles the concurrent tiles of one XCD span (0 = its run in row-major order)
-    unsigned* tile_ctr;  // gemm_pp.hip, persistent form: 8 per-XCD tile counters + the exit counter at [8] (all zero between launches) or null = tiles dealt statically
-    int stagger; // gemm_pp.hip, persistent form: start delay of every other workgroup of an XCD, in 10 ns (POLUS_GEMM_STAGGER_US x 100)
     const PolusDyn* dyn;  // per-step scalars in device memory (graph replay) or null: kernels with a dropout epilogue
                           // replace drop_seed by polus_eff_seed(drop_seed, dyn) on entry
 };

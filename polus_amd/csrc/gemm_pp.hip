@@ -206,16 +206,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
 template <int NT> struct PPPCfg {
     static constexpr int WN = 16 * NT;
     static constexpr int EPI = (EpiCfg<WN>::BYTES + 255) / 256 * 256;
-    static constexpr int NEXT = PPCfg<NT>::SMEM + 8 * EPI;     // one word: the next tile's index, from the wave that drew it to the others
-    static constexpr int SMEM = NEXT + 16;
+    static constexpr int SMEM = PPCfg<NT>::SMEM + 8 * EPI;
     static_assert(SMEM <= 160 * 1024, "two operand stages + the C staging of the 8 waves in one CU's LDS");
 };
 
 // The persistent loop of one workgroup.  `vb` of `vgrid`: this workgroup's index among those that share its tile list
 // (vb & 7 = blockIdx.x & 7, the XCD); the list = the 256 x TN tiles of columns [n_lo, n_hi) of C, n_hi <= p.N (rows past
-// p.M and columns past p.N are clamped / skipped as in gemm_pp_kernel).  ctr / exit_ctr: see GemmArgs::tile_ctr.
+// p.M and columns past p.N are clamped / skipped as in gemm_pp_kernel).
 template <int NT, bool DROP, int MODE>
-__device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgrid, const int n_lo, const int n_hi, unsigned* ctr) {
+__device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgrid, const int n_lo, const int n_hi) {
     typedef PPCfg<NT> C;
     constexpr int WN = C::WN, TN = C::TN, NB = C::NB, STAGE = C::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -268,16 +267,6 @@ __device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgr
     const int a_off = (wm * 128 + i) * 128;
     const int b_off = A_REGION + (wn * WN + i) * 128;
 
-    // Tiles: workgroup b starts on tile b.  Statically (tile_ctr null) it goes on with b + grid, b + 2 grid, ...; dynamically the
-    // workgroups of an XCD (b & 7) draw the further tiles of that XCD's list {t : t & 7 == b & 7} -- the same tiles in the same
-    // order, so an XCD still works on a few operand panels at a time -- from a counter, one returning atomic per tile, issued
-    // at the head of the tile and read behind its K loop.  When such a launch shares the chip -- the dU launch starts on the CUs
-    // the weight-gradient launch of the layer above leaves free, 88 us before the rest become free -- the early workgroups keep
-    // drawing tiles instead of stopping after their three (rocprofv3 timeline, profiles/r04_*).  Which workgroup computes a tile
-    // does not change its value.
-    const int xcd = vb & 7;
-    const int nwg_x = (vgrid - xcd + 7) >> 3;                   // workgroups on this tile list with the same b & 7
-    unsigned drawn = 0;
     int it = vb, trow, tcol;
     bool prev_interior = false;
     if (it >= ntiles) return;
@@ -285,23 +274,8 @@ __device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgr
     int m0 = trow * TM, n0 = n_lo + tcol * TN;
     set_tile(m0, n0);
     issue_prologue();
-    if (p.stagger > 0 && ((vb >> 3) & 1)) {
-        // Every other workgroup of an XCD starts p.stagger x 10 ns late (its first operands are already in flight).  All CUs
-        // walk equal tiles in step, so their epilogues -- 64 MB of HBM traffic per round of tiles on the GELU launches -- would
-        // all fall into the same few microseconds, in which no matrix instruction issues anywhere; half a phase apart, each
-        // half's burst passes under the other half's K loop.  The idle start is paid once, the bursts come once per tile:
-        // 6 us is worth -0.25 ... -0.47 % on the step on three boxes (interleaved A/B, tools/exp/stagger_ab.sh,
-        // profiles/r03_ab_stagger.txt); alone and from cold caches the dU launch gains 2 us and FFN1 forward moves by
-        // -0.5 ... +3 us depending on the box.
-        const unsigned long t0 = wall_clock64(), dt = (unsigned long)p.stagger;
-        while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
-    }
 
     for (; it < ntiles;) {
-        // (before the counted wait below: every vector-memory operation the K loop counts is younger than this one)
-        // (inline asm: hipcc's atomicAdd waits for the returned value -- vmcnt(0), the previous tile's store tail included -- on the spot)
-        if (ctr && tid == 0)
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(drawn) : "v"(ctr + xcd), "v"(1u) : "memory");
         f32x4 acc[8][NT];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
@@ -377,18 +351,7 @@ __device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgr
         // every wave is done with both operand stages and no DMA is in flight: the next tile's operands start now
         const int cm0 = m0, cn0 = n0;
         prev_interior = p.epi_vec16 && (cm0 + TM <= p.M) && (cn0 + TN <= p.N);
-        int nxt = it + vgrid;
-        if (ctr) {
-            typedef __attribute__((address_space(3))) int lds_int_t;
-            volatile lds_int_t* slot = (volatile lds_int_t*)(smem + PPPCfg<NT>::NEXT);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) :: "memory");     // (nothing else is outstanding behind the K loop's tail)
-            if (tid == 0) *slot = 8 * (nwg_x + (int)drawn) + xcd;
-            __syncthreads();
-            nxt = *slot;
-        }
-        // (the epilogue's bias / aux / residual loads are ordinary loads: hipcc waits vmcnt(0) at their first use while LDS-DMA
-        // is in flight, i.e. for the prologue as well.  Issuing the prologue FIRST keeps both in flight together; issuing it
-        // behind the bias loads -- so that the staging reads need not wait for it -- measured 5 % slower on the dU launch)
+        const int nxt = it + vgrid;
         it = nxt;
         if (it < ntiles) {
             tile_of(it, ntiles, tiles_n, p.order, trow, tcol);
@@ -401,21 +364,10 @@ __device__ __forceinline__ void ppp_run(GemmArgs& p, const int vb, const int vgr
     }
 }
 
-// the last workgroup out puts the counters back to zero for the next launch that is handed this block
-__device__ __forceinline__ void ppp_release_counters(unsigned* tile_ctr) {
-    if (tile_ctr && threadIdx.x == 0) {
-        if (atomicInc(tile_ctr + 8, gridDim.x - 1) == gridDim.x - 1) {
-#pragma unroll
-            for (int x = 0; x < 8; ++x) atomicExch(tile_ctr + x, 0u);
-        }
-    }
-}
-
 template <int NT, bool DROP, int MODE>
 __global__ __launch_bounds__(NTHR, 2) void gemm_ppp_kernel(GemmArgs p) {
     if (DROP) p.drop_seed = polus_eff_seed(p.drop_seed, p.dyn);
-    ppp_run<NT, DROP, MODE>(p, blockIdx.x, gridDim.x, 0, p.N, p.tile_ctr);
-    ppp_release_counters(p.tile_ctr);
+    ppp_run<NT, DROP, MODE>(p, blockIdx.x, gridDim.x, 0, p.N);
 }
 
 template <int NT, bool DROP, int MODE>
@@ -483,10 +435,8 @@ int polus_launch_gemm_pp(const GemmArgs& a, int mode, int drop, int tn, hipStrea
         // rounds, an epilogue too short to hide anything); POLUS_GEMM_PERSIST=2 forces it everywhere
         const bool wins = tn == 256 || a.persist_all;     // 192-wide launches lose with it (c5, 512 tiles of 256 x 192: 34.4 -> 34.8 ms/step)
         if (tiles > a.persist && wins) {
-            GemmArgs d = a;
-            d.tile_ctr = polus_cfg().gemm_dynamic ? polus_tile_counters() : nullptr;
-            if (tn == 256) return launch_ppp_mode<4>(d, mode, drop, a.persist, st);
-            if (tn == 192) return launch_ppp_mode<3>(d, mode, drop, a.persist, st);
+            if (tn == 256) return launch_ppp_mode<4>(a, mode, drop, a.persist, st);
+            if (tn == 192) return launch_ppp_mode<3>(a, mode, drop, a.persist, st);
         }
     }
     if (tn == 256) return launch_pp_mode<4>(a, mode, drop, st);

@@ -24,7 +24,6 @@ static void read_cfg() {
     g_cfg.gemm_v1 = getenv("POLUS_GEMM_V1") != nullptr;
     g_cfg.dw_ungrouped = getenv("POLUS_DW_UNGROUPED") != nullptr;
     g_cfg.gemm_order = env_int("POLUS_GEMM_ORDER", 4);
-    g_cfg.gemm_stagger_us = env_int("POLUS_GEMM_STAGGER_US", 6);
     g_cfg.reserve_cus = env_int("POLUS_GEMM_RESERVE_CUS", 0);
     g_cfg.gemm_persist = env_int("POLUS_GEMM_PERSIST", 1);
     g_cfg.dw_fused_reduce = env_int("POLUS_DW_FUSED_REDUCE", 1);
@@ -38,7 +37,6 @@ static void read_cfg() {
     g_cfg.ln_fin_single = env_int("POLUS_LN_FIN_SINGLE", 512);
     g_cfg.exp = env_int("POLUS_EXP", 0);
     g_cfg.dw_streamk = env_int("POLUS_DW_STREAMK", 0);
-    g_cfg.gemm_dynamic = env_int("POLUS_GEMM_DYNAMIC", 1);
     g_cfg.dw_sk_delta = env_int("POLUS_DW_SK_DELTA", 2);
     g_cfg.dw_sk_cus = env_int("POLUS_DW_SK_CUS", 0);
     g_cfg_ready = true;
@@ -63,24 +61,6 @@ int polus_num_cus() {
 static int g_reserve_on = 1;
 extern "C" int polus_set_reserve_active(int on) { g_reserve_on = on != 0; return POLUS_OK; }
 int polus_reserved_cus() { return g_reserve_on ? polus_cfg().reserve_cus : 0; }
-
-// Tile counters of the persistent GEMM launches: 64 blocks of 16 words per device, handed out in rotation.  A launch leaves its
-// block zeroed (its last workgroup resets it), so a block is reusable as soon as the launch that held it has finished -- with
-// in-order streams 64 launches later it has, unless more than 64 persistent GEMMs are in flight at once.
-unsigned* polus_tile_counters() {
-    constexpr int MAXDEV = 16, SLOTS = 64, WORDS = 16;     // 8 per-XCD tile counters, the exit counter at [8]
-    static unsigned* pool[MAXDEV] = {nullptr};
-    static unsigned next[MAXDEV] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
-    if (!pool[dev]) {
-        void* p = nullptr;
-        if (hipMalloc(&p, SLOTS * WORDS * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, SLOTS * WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-        pool[dev] = static_cast<unsigned*>(p);
-    }
-    return pool[dev] + (size_t)(next[dev]++ % SLOTS) * WORDS;
-}
 
 static const PolusDyn* g_dyn = nullptr;
 const PolusDyn* polus_dyn() { return g_dyn; }

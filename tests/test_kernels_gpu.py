@@ -769,11 +769,8 @@ def test_gemm_pingpong_persistent_equals_per_tile(ops, tn, M, N, K):
     try:
         for kw in cases:
             outs = []
-            # persistent with tiles drawn from the per-XCD counters (the default), persistent with tiles dealt statically, per tile;
-            # the first form twice: a launch must leave its counter block zeroed for the next one
-            for pers, dyn in ((2, 1), (2, 1), (2, 0), (0, 1)):
+            for pers in (2, 0):
                 ops.set_env("POLUS_GEMM_PERSIST", pers)
-                ops.set_env("POLUS_GEMM_DYNAMIC", dyn)
                 out = torch.full((M, N), float("nan"), dtype=dt, device="cuda")
                 kw2 = dict(kw)
                 if kw2.get("aux") == "new":
@@ -786,7 +783,7 @@ def test_gemm_pingpong_persistent_equals_per_tile(ops, tn, M, N, K):
                 if kw.get("aux") == "new":
                     assert torch.equal(outs[0][1], o[1])
     finally:
-        ops.set_env("POLUS_GEMM_PP"); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PERSIST"); ops.set_env("POLUS_GEMM_DYNAMIC")
+        ops.set_env("POLUS_GEMM_PP"); ops.set_env("POLUS_GEMM_RESERVE_CUS"); ops.set_env("POLUS_GEMM_PERSIST")
 
 
 @pytest.mark.parametrize("tn", [256, 192])
