@@ -19,7 +19,8 @@ timed region; achieved = algorithmic FLOPs of those launches / their summed devi
 the same run; `loss_at_step100` is BASELINE.json's loss@step100 for both engines (dropout 0).
 `cpu_baseline` times a torch-CPU eager fp32 restatement of the identical step (fwd + bwd + AdamW,
 oracle/bert_torch.py) on the host cores of this box, on a bounded sample (B=8, 3 + 5 steps): a reported
-baseline, not the target.
+baseline, not the target.  `roofline.traffic` (full default run, one GPU): HBM bytes per launch of that kernel family from two
+counters-only `rocprofv3 --pmc` passes over a 2-step child run of this script, started before this process touches the GPU.
 """
 import argparse
 import json
@@ -83,6 +84,56 @@ def self_launch(n, argv):
                     q.terminate()
         time.sleep(0.2)
     return rc
+
+
+def measure_hbm_traffic(extra_argv=()):
+    """roofline.traffic, live: HBM bytes per launch of the K-contiguous GEMM family from the PMC counters, collected as the
+    MI355X guide prescribes -- counters-only rocprofv3 passes (no trace domains), FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they
+    do not fit one), both in KiB, FETCH_SIZE doubled (gfx950 reports wide coalesced reads at half size), WRITE_SIZE exact.  Each pass
+    profiles a 2-step child run of THIS script; the children are started before this process has imported torch or touched the GPU,
+    with python3 itself behind `--`.  Returns a dict, or a string saying why there is no number (the line then carries null)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return "rocprofv3 not found"
+    sums, t_begin = {}, time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="polus_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-f32-leg", "--no-loss100", "--no-traffic"] + list(extra_argv)
+        env = dict(os.environ, TMPDIR="/tmp", POLUS_BENCH_CHILD="1")
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=max(30.0, 330.0 - (time.time() - t_begin)))
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)          # exactly the process group this call started
+                p.wait()
+                return f"the {counter} pass did not finish in time"
+            if rc != 0:
+                return f"the {counter} pass exited with code {rc}"
+            vals = []
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    n = r["Kernel_Name"]
+                    if r["Counter_Name"] == counter and ("gemm_pp_kernel" in n or "gemm_ppp_kernel" in n or "gemm_ring_kernelIDF16bLb0ELb0E" in n):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return f"the {counter} pass recorded no launch of the kernel family"
+            sums[counter] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    (f_kib, nf), (w_kib, nw) = sums["FETCH_SIZE"], sums["WRITE_SIZE"]
+    if nf != nw:
+        return f"the two passes saw different launch counts ({nf}, {nw})"
+    return {"bytes_per_launch": round((2.0 * f_kib + w_kib) * 1024.0), "FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
+            "launches_counted": nf, "seconds": round(time.time() - t_begin, 1),
+            "method": "two counters-only `rocprofv3 --pmc` child passes of this script (2 steps each): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, mean over the family's launches"}
 
 
 def tf_reference_probe():
@@ -322,6 +373,12 @@ def run_leg(args, dtype, steps, warmup, ctx, world, rank):
                               "their input gradients dX = dY.W^T-shadow; the remaining GEMMs are the K-strided dW = dY^T.X",
                     "launches": len(fwd), "avg_launch_us": round(tsum / len(fwd) * 1e6, 2),
                     "flops_per_launch": fsum / len(fwd)}
+            live = getattr(args, "traffic", None) if dtype == "bf16" else None
+            if isinstance(live, dict):
+                roof["traffic"] = live["bytes_per_launch"]
+                roof["traffic_measurement"] = live
+            elif isinstance(live, str):
+                roof["traffic_note"] = "no live number: " + live
             tf = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
             if dtype == "bf16" and os.path.exists(tf) and args.config == "c3" and (B, S, L, H) == (64, 256, 12, 768):
                 # NOT measured in this run: HBM bytes per launch of this kernel family from separate
@@ -415,11 +472,18 @@ def main():
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the reference-precision (f32 engine) leg")
     ap.add_argument("--no-loss100", action="store_true", help="skip the 2 x 100-step loss@step100 runs")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (launch-bound shapes, one GPU)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: nothing has touched torch or the GPU in this process
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    args.traffic = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_traffic and "POLUS_BENCH_CHILD" not in os.environ and
+            args.config == "c3" and args.dtype == "bf16" and args.batch is None and args.seq is None and args.layers == 12 and not args.large and
+            not (args.no_cpu_baseline or args.no_f32_leg or args.no_loss100) and "rocprof" not in os.environ.get("LD_PRELOAD", "")):
+        # (only the full default run -- what the driver executes -- pays for the two passes; the A/B and profile scripts shorten the run)
+        args.traffic = measure_hbm_traffic()          # before torch is imported: the children are the first to touch the GPU
 
     import torch
     from polus_amd import comm
