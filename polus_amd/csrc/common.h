@@ -48,7 +48,6 @@ struct PolusCfg {
     int dw_streamk;        // POLUS_DW_STREAMK: grouped dW with a stream-K remainder on the CUs the even K split leaves idle
     int dw_sk_cus;         // POLUS_DW_SK_CUS: CUs the stream-K grouped dW launch is planned for (0 = all that are not reserved)
     int dw_sk_delta;       // POLUS_DW_SK_DELTA: K-tiles a regular slice carries more than the even share (the remainder workgroups' extra epilogues)
-    int exp;               // POLUS_EXP: bit mask of experiments under measurement (tools/; every bit defaults to off)
     int attn_fused;        // POLUS_ATTN_FUSED: 1 (default) one-pass attention backward (bf16): 64-key blocks by LDS-DMA at S = 256, 32-key blocks at S = 64 / 128, key-resident from S = 512; 0 = two kernels
 };
 const PolusCfg& polus_cfg();

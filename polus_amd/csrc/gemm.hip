@@ -449,7 +449,6 @@ static int gemm_impl(int dtype, int a_layout, int b_layout, int c_dtype,
     if (resid) ev16 = ev16 && (((uintptr_t)resid) % 16 == 0) && ((ldr * es) % 16 == 0);
     if (aux) ev16 = ev16 && (((uintptr_t)aux) % 16 == 0) && ((ldaux * es) % 16 == 0);
     a.epi_vec16 = ev16 && dtype == POLUS_BF16;
-    a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;
@@ -600,7 +599,6 @@ extern "C" int polus_dense_bwd_params(int dtype, const void* dY, long lddy, cons
     const int splits_eff = (nkt + (a.k_per_split / bk) - 1) / (a.k_per_split / bk);
     a.a_vec = a.b_vec = 1;
     a.colsum_a = cs_ws;
-    a.exp = polus_cfg().exp;
     a.order = polus_cfg().gemm_order;
     a.persist = polus_cfg().gemm_persist ? max(32, polus_num_cus() - polus_reserved_cus()) : 0;
     a.persist_all = polus_cfg().gemm_persist >= 2;

@@ -23,7 +23,6 @@ struct GemmArgs {
     unsigned drop_thresh, drop_seed;
     float* colsum_a;      // ring kernel, A K-strided: per-split column sums of A, [splits][M] (bias gradient)
     long c_split_stride;  // elements between the C slabs of consecutive K-splits (ring kernel)
-    int exp;     // POLUS_EXP bits (experiments under measurement)
     int persist_all;  // POLUS_GEMM_PERSIST=2: the persistent form for every multi-round ping-pong launch (A/B)
     int persist; // gemm_pp.hip: > 0 = number of CUs for the persistent form of multi-round launches (POLUS_GEMM_PERSIST), 0 = one workgroup per tile
     int order;   // gemm_pp.hip: column tiles the concurrent tiles of one XCD span (0 = its run in row-major order)

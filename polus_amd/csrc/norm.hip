@@ -117,7 +117,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_hw_kernel(const bf16_t* __r
         load4<float>(beta + col, *reinterpret_cast<float(*)[4]>(&bv[c][0])); load4<float>(beta + col + 4, *reinterpret_cast<float(*)[4]>(&bv[c][4]));
     }
     const float invH = 1.0f / (float)H;
-    for (int row = (blockIdx.x * WAVES + wid) * 2 + half; row < rows; row += gridDim.x * WAVES * 2) {
+    const int nw = blockDim.x >> 6;                      // waves of this workgroup (the launch picks 4 or 16)
+    for (int row = (blockIdx.x * nw + wid) * 2 + half; row < rows; row += gridDim.x * nw * 2) {
         float v[NC][8];
         float s = 0.f;
 #pragma unroll
@@ -713,12 +714,16 @@ extern "C" int polus_layernorm_fwd(int dtype, const void* x, const float* gamma,
     int blocks = (rows + WAVES - 1) / WAVES;
     if (blocks > 4096) blocks = 4096;
     if (dtype == POLUS_BF16 && H % 256 == 0 && H <= 1024 && rows % 2 == 0 && polus_cfg().ln_halfwave) {
-        int hb = (rows / 2 + WAVES - 1) / WAVES;
-        if (hb > 4096) hb = 4096;
-        if (H == 256) hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
-        else if (H == 512) hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
-        else if (H == 768) hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
-        else hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, dim3(hb), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        // 4-wave workgroups: a 16-wave one (98 registers) fills a CU alone, so the launch ran as two rounds of 256 workgroups that all
+        // load, then all store; small workgroups keep five per CU in different phases (10.4 -> 9.4 us at 16384 x 768, tools/ln_bench.py, round 4)
+        const int fw = 4;
+        int hb = (rows / 2 + fw - 1) / fw;
+        if (hb > 16384) hb = 16384;
+        const int LN_THREADS_HW = 64 * fw;
+        if (H == 256) hipLaunchKernelGGL(ln_fwd_hw_kernel<1>, dim3(hb), dim3(LN_THREADS_HW), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        else if (H == 512) hipLaunchKernelGGL(ln_fwd_hw_kernel<2>, dim3(hb), dim3(LN_THREADS_HW), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        else if (H == 768) hipLaunchKernelGGL(ln_fwd_hw_kernel<3>, dim3(hb), dim3(LN_THREADS_HW), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
+        else hipLaunchKernelGGL(ln_fwd_hw_kernel<4>, dim3(hb), dim3(LN_THREADS_HW), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
     } else if (dtype == POLUS_BF16)
         POLUS_NC_DISPATCH(H, bf16_t, ln_fwd_kernel, dim3(blocks), dim3(LN_THREADS), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, H, eps);
     else if (dtype == POLUS_F32)

@@ -35,7 +35,6 @@ static void read_cfg() {
     g_cfg.gemm_ring128 = env_int("POLUS_GEMM_RING128", 0);
     g_cfg.ln_bwd_blocks = env_int("POLUS_LN_BWD_BLOCKS", 512);
     g_cfg.ln_fin_single = env_int("POLUS_LN_FIN_SINGLE", 512);
-    g_cfg.exp = env_int("POLUS_EXP", 0);
     g_cfg.dw_streamk = env_int("POLUS_DW_STREAMK", 0);
     g_cfg.dw_sk_delta = env_int("POLUS_DW_SK_DELTA", 2);
     g_cfg.dw_sk_cus = env_int("POLUS_DW_SK_CUS", 0);
