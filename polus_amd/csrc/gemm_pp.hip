@@ -157,6 +157,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_pp_kernel(GemmArgs p) {
         }
         read_a(t, P, 0);
         read_a(t, P, 1);
+        // (round 4: the same two loads issued BEHIND the barrier -- the R section then ends with the fragment reads alone -- is 1-6 %
+        // slower on every shape, profiles/r04_ab_dma_behind_barrier.txt: the DMA issue is better hidden beside the other group's MFMAs)
         if (P == 0 && TAIL <= 1) { load_a(t + 1, 3); if (NB == 4) load_b(t + 1, 3); }
         if (P >= 1 && TAIL == 0) { load_a(t + 2, P - 1); load_b(t + 2, P - 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers: their LDS region is free
