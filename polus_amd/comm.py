@@ -34,6 +34,7 @@ then rounded to bf16.
 The 1/world (and 1/accumulation) factor is folded into the optimizer's gradient scale instead of a
 separate pass."""
 import ctypes
+import logging
 import os
 
 import torch
@@ -258,7 +259,11 @@ def init():
         # tile rounds on 224 CUs as on 240 (192-, 216-, 576- and 768-tile launches), so the headroom for the exchange is free.  The reserve is switched on only around
         # backward (training.py _train_step): the forward pass runs beside no collective and keeps all 256 CUs.
         cap = os.environ.get("POLUS_RCCL_MAX_CHANNELS", "32")
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", cap)
+        if "NCCL_MAX_NCHANNELS" not in os.environ:
+            os.environ["NCCL_MAX_NCHANNELS"] = cap
+            # (process-wide: every other RCCL user of this process is capped as well -- say so once)
+            logging.getLogger("polus_amd").info("comm.init: NCCL_MAX_NCHANNELS=%s set for this process (POLUS_RCCL_MAX_CHANNELS; an explicit "
+                                                "NCCL_MAX_NCHANNELS in the environment is kept)", cap)
         if "POLUS_GEMM_RESERVE_CUS" not in os.environ:
             os.environ["POLUS_GEMM_RESERVE_CUS"] = os.environ["NCCL_MAX_NCHANNELS"]
             try:
