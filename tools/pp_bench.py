@@ -58,7 +58,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rnd = lambda r, c: (torch.rand(r, c, device=dev, generator=g) * 2 - 1).to(dt)
     # (name, N, K, epilogue)
-    shapes = [("qkv fwd", 3 * H, H, "bias"), ("out fwd", H, H, "drop+resid"), ("ffn1 fwd", I, H, "gelu+aux"),
+    shapes = [("qkv fwd", 3 * H, H, "bias"), ("out fwd", H, H, "drop+resid"), ("ffn1 fwd", I, H, "gelu+aux"), ("ffn1 noaux", I, H, "gelu"),
               ("ffn2 fwd", H, I, "drop+resid"), ("dx qkv", H, 3 * H, "resid"), ("dctx", H, H, "plain"),
               ("du (ffn2 dx)", I, H, "gelu-bwd"), ("da1 (ffn1 dx)", H, I, "resid")]
     if args.only:
@@ -78,6 +78,7 @@ def main():
         kw = {"bias": dict(bias=bias), "plain": dict(), "resid": dict(resid=res),
               "drop+resid": dict(bias=bias, resid=res, drop_p=0.1, seed=5),
               "gelu+aux": dict(bias=bias, aux=aux, act="gelu", flags=ops.GEMM_ACT_FWD),
+              "gelu": dict(bias=bias, act="gelu", flags=ops.GEMM_ACT_FWD),
               "gelu-bwd": dict(aux=aux, act="gelu", flags=ops.GEMM_ACT_BWD)}[epi]
         fn = lambda: ops.gemm(a, b, c, **kw)
         fl = 2.0 * T * N * K
