@@ -537,6 +537,7 @@ class BertModel(SavableModel):
             B, S = hs.shape[0], hs.shape[1]
             hidden = hs.reshape(B * S, -1)
         self._shape = (B, S)
+        self.tokens_per_step = B * S          # training.py: whether the optimizer update rides inside backward
         hidden = self.encode(hidden, attention_mask, B, S, training)
         if training:
             self.dropout_step += 1
@@ -662,6 +663,7 @@ class TFBertSplited(PolusModel):
         if train:
             self.dropout_step += 1
         self._shape = (B, S)
+        self.tokens_per_step = B * S          # training.py: whether the optimizer update rides inside backward
         h3 = hidden.view(B, S, H)
         return BaseModelOutputWithPooling(last_hidden_state=h3, pooler_output=h3[:, 0, :])
 

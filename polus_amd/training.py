@@ -185,7 +185,8 @@ class BaseTrainer:
     def _updater(self):
         """The in-backward optimizer update (see _UpdateInBackward), when nothing needs all gradients at once: one
         process, one arena on the GPU swept by the fused Adam, no post_process_grads, no global-norm clipping, no
-        step graph (its eager warm-up steps must take the path that is captured).  POLUS_UPDATE_IN_BACKWARD=0 keeps
+        step graph (its eager warm-up steps must take the path that is captured), and -- unless POLUS_UPDATE_IN_BACKWARD=1 --
+        at least 6144 tokens per step (below, the windows outlast the launches they hide under).  POLUS_UPDATE_IN_BACKWARD=0 keeps
         the single launch after backward; `trainer.update_in_backward = False` does the same for the steps that
         follow (bench.py's instrumented single-stream step)."""
         if getattr(self, "_graphed", None) is not None or not getattr(self, "update_in_backward", True):
@@ -201,6 +202,15 @@ class BaseTrainer:
                   self.post_process_grads is None and hasattr(arenas[0], "refresh_transposed") and
                   arenas[0].grads.is_cuda and all(v.arena is arenas[0] for v in self.trainable_weights))
             u = self._updater_cached = _UpdateInBackward(self, arenas[0]) if ok else None
+        if u is not None and "POLUS_UPDATE_IN_BACKWARD" not in os.environ:
+            # By size, unless the switch says 0 / 1: a layer's update window (its parameters' 213 MB for BERT-base, whatever the
+            # batch) rides on the CUs the weight-gradient launch of the layer below leaves free, and that launch shrinks with the
+            # tokens per step: 247 us at 16384 tokens, 87 us at 4096 -- there the window outlasts it and lands on the next dU GEMM
+            # (BASELINE configs[1], B=32 S=128: 5.56 -> 5.44 ms per step with the one launch after backward; neutral at 8192 tokens;
+            # at 16384 the in-backward form wins, 12.48 -> 12.27 ms in round 2).
+            tokens = getattr(self.model, "tokens_per_step", None)
+            if tokens is not None and tokens < 6144:
+                return None
         return u
 
     def _updater_dp(self, reducer):
